@@ -1,0 +1,159 @@
+"""Synthetic scene + camera generator for the benchmark and the parity tests.
+
+Restates the conventions the rasterizer's callers use in the reference (nothing here is on the
+hot path):
+  * camera matrices      scene/cameras.py:48-57, utils/graphics_utils.py:67-87
+                         (world_view_transform and full_proj_transform are stored TRANSPOSED)
+  * 3D (mip) filter      scene/gaussian_model.py:156-166 (applied outside the op, in the caller)
+  * argument shapes      gaussian_renderer/__init__.py:56-79
+Distributions follow SURVEY.md section 8(d).  Everything is generated on the CPU from a
+seeded torch.Generator so that every rank / box sees identical inputs; move with `.to(device)`.
+"""
+import math
+from typing import NamedTuple, Optional
+
+import torch
+
+# BASELINE.json configs: name -> (P, W, H, sh_degree, mu_px, mode, seed)
+CONFIGS = {
+    "C1": dict(P=10_000, W=256, H=256, sh_degree=0, mu_px=1.5, require_coord=False, require_depth=True, seed=0),
+    "C2": dict(P=1_000_000, W=1920, H=1080, sh_degree=3, mu_px=1.5, require_coord=False, require_depth=True, seed=1),
+    "C3": dict(P=1_000_000, W=1600, H=1200, sh_degree=3, mu_px=1.5, require_coord=False, require_depth=True, seed=100),
+    "C4": dict(P=5_000_000, W=1920, H=1080, sh_degree=3, mu_px=1.5, require_coord=True, require_depth=False, seed=4),
+    "C5": dict(P=500_000, W=3840, H=2160, sh_degree=3, mu_px=12.0, require_coord=False, require_depth=True, seed=5,
+               low_opacity=True),
+}
+
+
+class Scene(NamedTuple):
+    means3D: torch.Tensor      # (P,3)
+    opacities: torch.Tensor    # (P,1) already multiplied by the 3D-filter coefficient
+    scales: torch.Tensor       # (P,3) already 3D-filtered
+    rotations: torch.Tensor    # (P,4) normalised (r,x,y,z)
+    shs: torch.Tensor          # (P,16,3)
+    viewmatrix: torch.Tensor   # (4,4) transposed world->view
+    projmatrix: torch.Tensor   # (4,4) transposed full projection
+    campos: torch.Tensor       # (3,)
+    bg: torch.Tensor           # (3,)
+    tanfovx: float
+    tanfovy: float
+    W: int
+    H: int
+    sh_degree: int
+    kernel_size: float
+    require_coord: bool
+    require_depth: bool
+
+
+def projection_matrix(znear, zfar, fovx, fovy):
+    """utils/graphics_utils.py:67-87 (returned un-transposed, like the reference)."""
+    t = math.tan(fovy / 2) * znear
+    r = math.tan(fovx / 2) * znear
+    P = torch.zeros(4, 4)
+    P[0, 0] = 2.0 * znear / (2 * r)
+    P[1, 1] = 2.0 * znear / (2 * t)
+    P[3, 2] = 1.0
+    P[2, 2] = zfar / (zfar - znear)
+    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    return P
+
+
+def _rand_rotation(gen):
+    q = torch.randn(4, generator=gen)
+    q = q / q.norm()
+    r, x, y, z = q.tolist()
+    return torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)],
+                         [2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)],
+                         [2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]])
+
+
+def make_scene(P, W, H, sh_degree=3, mu_px=1.5, seed=0, kernel_size=0.0, require_coord=False, require_depth=True,
+               low_opacity=False, pose="identity", fovx_deg=60.0, bg=(0.0, 0.0, 0.0), near_cull_frac=0.02,
+               filter3d=True) -> Scene:
+    gen = torch.Generator().manual_seed(int(seed))
+    tanfovx = math.tan(math.radians(fovx_deg) * 0.5)
+    tanfovy = tanfovx * H / W
+    fovx, fovy = 2 * math.atan(tanfovx), 2 * math.atan(tanfovy)
+    focal_x = W / (2 * tanfovx)
+
+    # camera pose: world->view rotation Rw2c and translation T (view = Rw2c @ x + T)
+    if pose == "identity":
+        Rw2c, T = torch.eye(3), torch.zeros(3)
+    else:
+        Rw2c = _rand_rotation(gen)
+        T = torch.randn(3, generator=gen) * 0.5
+    w2c = torch.eye(4)
+    w2c[:3, :3] = Rw2c
+    w2c[:3, 3] = T
+    viewmatrix = w2c.transpose(0, 1).contiguous()                      # scene/cameras.py:54
+    proj = projection_matrix(0.01, 100.0, fovx, fovy).transpose(0, 1)  # scene/cameras.py:55
+    projmatrix = (viewmatrix @ proj).contiguous()                      # scene/cameras.py:56
+    campos = torch.linalg.inv(viewmatrix)[3, :3].contiguous()          # scene/cameras.py:57
+
+    def U(n, lo, hi):
+        return torch.rand(n, generator=gen) * (hi - lo) + lo
+
+    z = U(P, 2.0, 10.0)
+    ncull = int(P * near_cull_frac)
+    if ncull:
+        z[:ncull] = U(ncull, -1.0, 0.2)
+        perm = torch.randperm(P, generator=gen)
+        z = z[perm]
+    zz = z.abs().clamp_min(0.3)  # lateral extent also for culled points
+    x = zz * tanfovx * U(P, -1.1, 1.1)
+    y = zz * tanfovy * U(P, -1.1, 1.1)
+    cam_pts = torch.stack([x, y, z], 1)
+    means3D = (cam_pts - T) @ Rw2c  # = Rw2c^T (p - T), row-vector form
+
+    sigma_px = torch.exp(math.log(mu_px) + 0.6 * torch.randn(P, generator=gen))
+    aniso = torch.exp(0.5 * torch.randn(P, 3, generator=gen))
+    scales = (zz * sigma_px / focal_x)[:, None] * aniso
+    if low_opacity:
+        opacity = U(P, 0.02, 0.3)[:, None]
+    else:
+        opacity = torch.sigmoid(2.0 * torch.randn(P, 1, generator=gen))
+    if filter3d:  # scene/gaussian_model.py:156-166 with filter_3D = z/focal * sqrt(0.2)
+        filt = (zz / focal_x * math.sqrt(0.2))[:, None]
+        s2 = scales * scales
+        det1 = s2.prod(1)
+        s2f = s2 + filt * filt
+        det2 = s2f.prod(1)
+        opacity = opacity * torch.sqrt(det1 / det2)[:, None]
+        scales = torch.sqrt(s2f)
+    q = torch.randn(P, 4, generator=gen)
+    rotations = q / q.norm(dim=1, keepdim=True)
+    shs = torch.cat([torch.randn(P, 1, 3, generator=gen), 0.1 * torch.randn(P, 15, 3, generator=gen)], 1)
+    return Scene(means3D.float().contiguous(), opacity.float().contiguous(), scales.float().contiguous(),
+                 rotations.float().contiguous(), shs.float().contiguous(), viewmatrix.float(), projmatrix.float(),
+                 campos.float(), torch.tensor(bg, dtype=torch.float32), tanfovx, tanfovy, W, H, sh_degree,
+                 float(kernel_size), bool(require_coord), bool(require_depth))
+
+
+def make_config(name, **over) -> Scene:
+    kw = dict(CONFIGS[name])
+    kw.update(over)
+    return make_scene(**kw)
+
+
+def upstream_grads(scene: Scene, seed=0):
+    """Fixed random cotangents w_k for the 7 image outputs (loss = sum_k <w_k, out_k>)."""
+    gen = torch.Generator().manual_seed(10_000 + int(seed))
+    H, W = scene.H, scene.W
+
+    def n(c):
+        return torch.randn(c, H, W, generator=gen)
+
+    g = dict(color=n(3), coord=n(3), mcoord=n(3), depth=n(1), mdepth=n(1), alpha=n(1), normal=n(3))
+    if not scene.require_coord:
+        g["coord"].zero_()
+        g["mcoord"].zero_()
+    if not scene.require_depth:
+        g["depth"].zero_()
+        g["mdepth"].zero_()
+    if not (scene.require_coord or scene.require_depth):
+        g["normal"].zero_()
+    return g
+
+
+def to_device(scene: Scene, device) -> Scene:
+    return Scene(*[v.to(device) if isinstance(v, torch.Tensor) else v for v in scene])
