@@ -1,0 +1,150 @@
+/* radegs.h -- C ABI of libradegs_hip.so, the MI355X (gfx950) differentiable Gaussian-splat
+ * rasterizer behind RaDe-GS's `diff_gaussian_rasterization` operator.
+ *
+ * This is the drop-in boundary for the one hot path this repository accelerates.  Every entry
+ * point replaces one static method of the reference's native interface
+ * (DGR = /root/reference/submodules/diff-gaussian-rasterization):
+ *
+ *   radegs_forward       <-  CudaRasterizer::Rasterizer::forward    DGR/cuda_rasterizer/rasterizer.h:33-68
+ *                            (called from RasterizeGaussiansCUDA,    DGR/rasterize_points.cu:36-133)
+ *   radegs_backward      <-  CudaRasterizer::Rasterizer::backward   DGR/cuda_rasterizer/rasterizer.h:99-146
+ *                            (called from RasterizeGaussiansBackwardCUDA, DGR/rasterize_points.cu:136-246)
+ *   radegs_mark_visible  <-  CudaRasterizer::Rasterizer::markVisible DGR/cuda_rasterizer/rasterizer.h:26-31
+ *                            (called from markVisible,               DGR/rasterize_points.cu:248-267)
+ *
+ * Conventions kept from the reference:
+ *   - plain device pointers + sizes; NULL means "tensor not provided" (the reference tests
+ *     data_ptr()==nullptr: forward.cu:363,407, backward.cu:622,626, rasterizer_impl.cu:394,494,540);
+ *   - the three scratch buffers (geometry / binning / image state) are obtained through
+ *     allocator callbacks -- the C form of std::function<char*(size_t)> -- so the caller owns
+ *     the memory (torch tensors in the Python binding), may keep it for backward, and hands the
+ *     same pointers back.  Their internal layout is private and self-describing from (P, R, W*H);
+ *   - viewmatrix/projmatrix are the transposed 4x4 float matrices the reference passes;
+ *   - image outputs are CHW float32; `radii` is int32[P].
+ * Differences, all deliberate:
+ *   - every call takes a HIP stream (the reference launches on the legacy default stream);
+ *   - errors are returned as negative codes + radegs_last_error() instead of C++ exceptions;
+ *   - output images for modes that are switched off are not touched (the binding zero-fills
+ *     them, as the reference's torch::full does).
+ * No torch types appear here; `stream` is a hipStream_t passed as void*.
+ */
+#ifndef RADEGS_H_INCLUDED
+#define RADEGS_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RADEGS_OK 0
+#define RADEGS_ERR_INVALID_ARG (-1)
+#define RADEGS_ERR_ALLOC (-2)
+#define RADEGS_ERR_HIP (-3)
+#define RADEGS_ERR_NO_DEVICE (-4)
+
+/* Allocator callback: return a DEVICE pointer to at least `nbytes` bytes (256-B aligned), or
+ * NULL on failure.  Mirrors the resize lambdas of DGR/rasterize_points.cu:27-33. */
+typedef void* (*radegs_alloc_fn)(void* user, size_t nbytes);
+
+typedef struct RadegsFwdArgs {
+  int P;              /* number of Gaussians */
+  int D;              /* active SH degree */
+  int M;              /* SH coefficients per Gaussian in `shs` (rows of the (P,M,3) tensor) */
+  int width, height;
+  const float* background;      /* [3] device */
+  const float* means3D;         /* [P,3] */
+  const float* shs;             /* [P,M,3] or NULL */
+  const float* colors_precomp;  /* [P,3] or NULL (exactly one of shs / colors_precomp) */
+  const float* opacities;       /* [P] */
+  const float* scales;          /* [P,3] or NULL */
+  const float* rotations;       /* [P,4] (r,x,y,z), not normalised here; or NULL */
+  const float* cov3D_precomp;   /* [P,6] or NULL (exactly one of scales+rotations / cov3D) */
+  const float* viewmatrix;      /* [16] device, transposed */
+  const float* projmatrix;      /* [16] device, transposed */
+  const float* cam_pos;         /* [3] device */
+  float scale_modifier, tan_fovx, tan_fovy, kernel_size;
+  int prefiltered;              /* must be 0 */
+  int require_coord, require_depth, debug;
+  float* out_color;             /* [3,H,W] */
+  float* out_coord;             /* [3,H,W]  written iff require_coord */
+  float* out_mcoord;            /* [3,H,W]  written iff require_coord */
+  float* out_depth;             /* [1,H,W]  written iff require_depth */
+  float* out_mdepth;            /* [1,H,W]  written iff require_depth */
+  float* out_alpha;             /* [1,H,W] */
+  float* out_normal;            /* [3,H,W]  written iff require_coord || require_depth */
+  int* radii;                   /* [P] */
+} RadegsFwdArgs;
+
+/* Returns num_rendered (>= 0) or a negative RADEGS_ERR_*.  Synchronises the stream once (the
+ * 4-byte read-back of num_rendered that sizes the binning buffer, like rasterizer_impl.cu:354). */
+int radegs_forward(const RadegsFwdArgs* args, radegs_alloc_fn geom_alloc, void* geom_user, radegs_alloc_fn binning_alloc,
+                   void* binning_user, radegs_alloc_fn image_alloc, void* image_user, void* stream);
+
+typedef struct RadegsBwdArgs {
+  int P, D, M, R;               /* R = num_rendered returned by the forward */
+  int width, height;
+  const float* background;
+  const float* means3D;
+  const float* shs;
+  const float* colors_precomp;
+  const float* alphas;          /* out_alpha of the forward */
+  const float* scales;
+  const float* rotations;
+  const float* cov3D_precomp;
+  const float* viewmatrix;
+  const float* projmatrix;
+  const float* cam_pos;
+  float scale_modifier, tan_fovx, tan_fovy, kernel_size;
+  const int* radii;
+  const float* normalmap;       /* out_normal of the forward */
+  void* geom_buffer;            /* the three buffers the forward filled */
+  void* binning_buffer;
+  void* image_buffer;
+  const float* dL_dpix;         /* [3,H,W] */
+  const float* dL_dpix_coord;   /* [3,H,W] */
+  const float* dL_dpix_mcoord;  /* [3,H,W] */
+  const float* dL_dpix_depth;   /* [1,H,W] */
+  const float* dL_dpix_mdepth;  /* [1,H,W] */
+  const float* dL_dalphas;      /* [1,H,W] */
+  const float* dL_dpix_normal;  /* [3,H,W] */
+  /* outputs; every element is written by the call (no pre-zeroing needed) */
+  float* dL_dmean2D;            /* [P,3]  x,y signed, z = abs-grad sum */
+  float* dL_dcolor;             /* [P,3] */
+  float* dL_dopacity;           /* [P,1] */
+  float* dL_dmean3D;            /* [P,3] */
+  float* dL_dcov3D;             /* [P,6] */
+  float* dL_dsh;                /* [P,M,3] or NULL when M == 0 */
+  float* dL_dscale;             /* [P,3] */
+  float* dL_drot;               /* [P,4] */
+  int require_coord, require_depth, debug;
+} RadegsBwdArgs;
+
+/* `accum_alloc` provides the per-Gaussian accumulation scratch (64 or 128 B per Gaussian). */
+int radegs_backward(const RadegsBwdArgs* args, radegs_alloc_fn accum_alloc, void* accum_user, void* stream);
+
+/* present[i] = 1 iff Gaussian i passes the near-plane test (view z > 0.2). */
+int radegs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, unsigned char* present,
+                        void* stream);
+
+/* Sizes of the geometry / image state for (P) and (W*H) -- the binning size depends on R and is
+ * requested through the callback. */
+size_t radegs_geometry_bytes(int P, int require_coord);
+size_t radegs_image_bytes(int width, int height);
+size_t radegs_binning_bytes(int R);
+
+/* Test/inspection hook: copy a named private array out of the state buffers into `dst`
+ * (device memory, dst_bytes large enough).  Names: "point_list" u32[R], "ranges" u32[2*tiles],
+ * "n_contrib" u32[2*H*W], "tiles_touched" u32[P], "splat_a" f32[P,16], "splat_b" f32[P,12],
+ * "clamped" u8[P], "depth_key" u32[P].  Returns bytes copied or a negative error. */
+long long radegs_debug_export(const char* name, int P, int R, int width, int height, int require_coord, const void* geom_buffer,
+                              const void* binning_buffer, const void* image_buffer, void* dst, size_t dst_bytes, void* stream);
+
+const char* radegs_last_error(void);
+const char* radegs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RADEGS_H_INCLUDED */

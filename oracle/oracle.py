@@ -41,6 +41,8 @@ def lib():
         L.oracle_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_longlong]
         L.oracle_stat_pairs.restype = ctypes.c_longlong
         L.oracle_stat_pairs.argtypes = [ctypes.c_void_p]
+        L.oracle_stat_blended.restype = ctypes.c_longlong
+        L.oracle_stat_blended.argtypes = [ctypes.c_void_p]
         L.oracle_destroy.restype = None
         L.oracle_destroy.argtypes = [ctypes.c_void_p]
         L.oracle_mark_visible.restype = None
@@ -137,6 +139,9 @@ class Oracle:
 
     def stat_pairs(self):
         return lib().oracle_stat_pairs(self._h)
+
+    def stat_blended(self):
+        return lib().oracle_stat_blended(self._h)
 
     def close(self):
         if self._h:

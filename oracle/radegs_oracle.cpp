@@ -224,7 +224,8 @@ template <class R> struct Oracle {
       dL_dnormals, dL_dconic, dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations;
   // render-bwd per-Gaussian accumulators before the per-Gaussian chain rule (kept for tests)
   std::vector<R> acc_dmeans2D, acc_dconic, acc_dopacity, acc_dcolors;
-  int64_t stat_pairs_fwd = 0;  // (pixel, list entry) pairs visited by the forward blend
+  int64_t stat_pairs_fwd = 0;    // (pixel, list entry) pairs visited by the forward blend
+  int64_t stat_blended_fwd = 0;  // pairs that passed every threshold and were blended
 
   std::map<std::string, std::pair<const void*, size_t>> registry;
   template <class T> void reg(const char* name, const std::vector<T>& v) {
@@ -413,7 +414,7 @@ template <class R> struct Oracle {
   }
 
   // renderCUDA<3,COORD,DEPTH,NORMAL> fwd for one pixel, forward.cu:428-693
-  void render_pixel(uint32_t px, uint32_t py, bool COORD, bool DEPTH, bool NORMAL, int64_t& pairs) {
+  void render_pixel(uint32_t px, uint32_t py, bool COORD, bool DEPTH, bool NORMAL, int64_t& pairs, int64_t& blended) {
     const bool GEO = DEPTH || COORD || NORMAL;
     const size_t HW = size_t(H) * W;
     const uint32_t pix_id = W * py + px;
@@ -440,6 +441,7 @@ template <class R> struct Oracle {
       const R test_T = T * (1 - alpha);
       if (test_T < R(0.0001f)) break;  // done = true
       const R aT = alpha * T;
+      blended++;
       for (int ch = 0; ch < 3; ch++) C[ch] += feat[3 * g + ch] * aT;
       const bool before_median = T > R(0.5);
       if (COORD) {
@@ -512,14 +514,15 @@ template <class R> struct Oracle {
       bin_and_sort();
       // template dispatch, forward.cu:732-739
       const bool COORD = req_coord, DEPTH = req_depth, NORMAL = req_coord || req_depth;
-      int64_t pairs = 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : pairs) num_threads(nthreads)
+      int64_t pairs = 0, blended = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : pairs, blended) num_threads(nthreads)
       for (int tile = 0; tile < gx * gy; tile++) {
         const int ty = tile / gx, tx = tile % gx;
         for (int y = ty * TILE; y < std::min((ty + 1) * TILE, H); y++)
-          for (int x = tx * TILE; x < std::min((tx + 1) * TILE, W); x++) render_pixel(x, y, COORD, DEPTH, NORMAL, pairs);
+          for (int x = tx * TILE; x < std::min((tx + 1) * TILE, W); x++) render_pixel(x, y, COORD, DEPTH, NORMAL, pairs, blended);
       }
       stat_pairs_fwd = pairs;
+      stat_blended_fwd = blended;
     } else {
       // P == 0: every output stays at its zero fill (the reference skips the whole call)
     }
@@ -1081,6 +1084,10 @@ long long oracle_get(void* hv, const char* name, void* dst, long long nbytes) {
 long long oracle_stat_pairs(void* hv) {
   auto* h = static_cast<Handle*>(hv);
   return h->d ? h->d->stat_pairs_fwd : h->f->stat_pairs_fwd;
+}
+long long oracle_stat_blended(void* hv) {
+  auto* h = static_cast<Handle*>(hv);
+  return h->d ? h->d->stat_blended_fwd : h->f->stat_blended_fwd;
 }
 
 void oracle_destroy(void* hv) {

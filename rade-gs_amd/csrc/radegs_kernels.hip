@@ -1,0 +1,676 @@
+// radegs_kernels.hip -- gfx950 kernels of the differentiable splat rasterizer.
+//
+// Stage map (reference kernel -> this file); DGR = submodules/diff-gaussian-rasterization:
+//   preprocessCUDA<3,false>   DGR/cuda_rasterizer/forward.cu:307-423        -> preprocess_fwd_kernel
+//   duplicateWithKeys         DGR/cuda_rasterizer/rasterizer_impl.cu:70-111 -> emit_instances_kernel
+//   identifyTileRanges        rasterizer_impl.cu:151-173                    -> tile_ranges_kernel
+//   renderCUDA fwd            forward.cu:428-693                            -> blend_fwd_kernel
+//   renderCUDA bwd            DGR/cuda_rasterizer/backward.cu:631-1016      -> blend_bwd_kernel
+//   computeCov2DCUDA + preprocessCUDA bwd  backward.cu:145-488,560-628      -> preprocess_bwd_kernel
+//   checkFrustum              rasterizer_impl.cu:54-66                      -> mark_visible_kernel
+//
+// Design for CDNA4 (not a translation of the CUDA block structure):
+//   * Blend kernels: ONE wave64 owns a 16 x (4*PPL) pixel strip of a 16x16 tile; each lane keeps
+//     PPL pixels (same column, rows 4 apart) in registers.  No cross-wave sharing, no barriers in
+//     the hot loop.  Per-Gaussian attributes are wave-uniform: they are staged 64 entries at a
+//     time into wave-private LDS (each lane gathers one 64-B record = one cache line) and read
+//     back as broadcast ds_read_b128 -- amortised over PPL pixels per lane, which keeps the
+//     LDS pipe (one b128 per 4 clk per CU) off the critical path.
+//   * The skip test needs no transcendental: a per-Gaussian exponent threshold (computed once in
+//     preprocess) rejects alpha < 1/255 pairs from the quadratic form alone; exp is evaluated
+//     only for surviving pairs, with the specified exp_spec() so that every thresholded decision
+//     matches the CPU oracle bit-for-bit.
+//   * Backward: per-lane partial gradients of one Gaussian are reduced with a butterfly that
+//     reduces all 16 (or 32) gradient components at once (15 + 2 cross-lane exchanges instead of
+//     16 x 6) and leaves component c in lane c, so ONE 16/25-lane global_atomic_add_f32
+//     instruction updates one 64-B accumulator line.
+//   * blockIdx -> tile mapping gives each XCD a contiguous band of tiles (neighbouring tiles
+//     share splat records -> per-XCD L2 reuse).
+// No MFMA: there is no dense contraction on this path.
+#include <hip/hip_runtime.h>
+
+#include "rg_blend.h"
+#include "rg_layout.h"
+#include "rg_preprocess.h"
+#include "rg_preprocess_bwd.h"
+
+namespace rg {
+
+// ------------------------------------------------------------------ launch arguments ----
+struct CamArgs {
+  const float* view;    // device [16]
+  const float* proj;    // device [16]
+  const float* campos;  // device [3]
+  float focal_x, focal_y, tan_fovx, tan_fovy, kernel_size, scale_modifier;
+  int W, H, gx, gy;
+};
+
+__device__ __forceinline__ Camera load_camera(const CamArgs& a) {
+  Camera c;
+#pragma unroll
+  for (int i = 0; i < 16; i++) { c.view[i] = a.view[i]; c.proj[i] = a.proj[i]; }
+#pragma unroll
+  for (int i = 0; i < 3; i++) c.campos[i] = a.campos[i];
+  c.focal_x = a.focal_x; c.focal_y = a.focal_y; c.tan_fovx = a.tan_fovx; c.tan_fovy = a.tan_fovy;
+  c.kernel_size = a.kernel_size; c.scale_modifier = a.scale_modifier;
+  c.W = a.W; c.H = a.H; c.gx = a.gx; c.gy = a.gy;
+  return c;
+}
+
+// =========================================================================== preprocess ==
+struct PreFwdArgs {
+  int P, D, M;
+  const float* means3D; const float* scales; const float* rotations; const float* cov3D_precomp;
+  const float* opacities; const float* shs; const float* colors_precomp;
+  CamArgs cam;
+  int write_b;
+  int* radii; float4* splat_a; float4* splat_b; uint32_t* tiles_touched; uint32_t* depth_key; uint8_t* clamped;
+};
+
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(const PreFwdArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.P) return;
+  const Camera cam = load_camera(a.cam);
+  SplatFwd s;
+  const float* m = a.means3D + 3 * (size_t)idx;
+  preprocess_fwd(mk3(m[0], m[1], m[2]), a.scales ? a.scales + 3 * (size_t)idx : nullptr,
+                 a.rotations ? a.rotations + 4 * (size_t)idx : nullptr, a.cov3D_precomp ? a.cov3D_precomp + 6 * (size_t)idx : nullptr,
+                 a.opacities[idx], a.D, a.shs ? a.shs + (size_t)idx * a.M * 3 : nullptr,
+                 a.colors_precomp ? a.colors_precomp + 3 * (size_t)idx : nullptr, cam, s);
+  a.radii[idx] = s.radius;
+  a.tiles_touched[idx] = (uint32_t)s.tiles;
+  // positive floats order like unsigned ints; invisible Gaussians sort to the very end
+  a.depth_key[idx] = s.radius > 0 ? __float_as_uint(s.depth) : 0xFFFFFFFFu;
+  if (s.radius > 0) {
+    float4* ra = a.splat_a + 4 * (size_t)idx;
+    ra[0] = make_float4(s.mx, s.my, s.cx, s.cy);
+    ra[1] = make_float4(s.cz, s.op, skip_threshold(s.op), s.ts);
+    ra[2] = make_float4(s.rgb[0], s.rgb[1], s.rgb[2], s.rp[0]);
+    ra[3] = make_float4(s.rp[1], s.nrm[0], s.nrm[1], s.nrm[2]);
+    if (a.write_b) {
+      float4* rb = a.splat_b + 3 * (size_t)idx;
+      rb[0] = make_float4(s.cp[0], s.cp[1], s.cp[2], s.cp[3]);
+      rb[1] = make_float4(s.cp[4], s.cp[5], s.vp[0], s.vp[1]);
+      rb[2] = make_float4(s.vp[2], 0.f, 0.f, 0.f);
+    }
+    a.clamped[idx] = (uint8_t)s.clamped;
+  }
+}
+
+__global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* means3D, const float* view, unsigned char* present) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P) return;
+  const float* m = means3D + 3 * (size_t)idx;
+  v3 pv = xform43(mk3(m[0], m[1], m[2]), view);
+  present[idx] = !(pv.z <= 0.2f);
+}
+
+// ============================================================================== binning ==
+// One thread per Gaussian IN DEPTH ORDER; writes (tile id, gaussian idx) for every tile of its
+// rect, rows outer / columns inner -- the emission order of rasterizer_impl.cu:98-109.
+__global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32_t* idx_sorted, const uint32_t* offsets,
+                                                            const uint32_t* tiles_touched, const float4* splat_a, const int* radii,
+                                                            int gx, int gy, uint32_t* tile_keys, uint32_t* vals) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const uint32_t idx = idx_sorted[i];
+  if (tiles_touched[idx] == 0) return;
+  uint32_t off = (i == 0) ? 0u : offsets[i - 1];
+  const float4 a0 = splat_a[4 * (size_t)idx];
+  int x0, y0, x1, y1;
+  tile_rect(a0.x, a0.y, radii[idx], gx, gy, x0, y0, x1, y1);
+  for (int y = y0; y < y1; y++)
+    for (int x = x0; x < x1; x++) {
+      tile_keys[off] = (uint32_t)(y * gx + x);
+      vals[off] = idx;
+      off++;
+    }
+}
+
+__global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint32_t* keys, uint2* ranges) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= L) return;
+  const uint32_t cur = keys[i];
+  if (i == 0) ranges[cur].x = 0;
+  else {
+    const uint32_t prev = keys[i - 1];
+    if (cur != prev) { ranges[prev].y = i; ranges[cur].x = i; }
+  }
+  if (i == L - 1) ranges[cur].y = L;
+}
+
+// =========================================================================== blend, fwd ==
+struct BlendFwdArgs {
+  const uint2* ranges; const uint32_t* point_list; const float4* splat_a; const float4* splat_b;
+  int W, H, gx, ntiles; float focal_x, focal_y;
+  const float* bg;
+  float* out_color; float* out_coord; float* out_mcoord; float* out_depth; float* out_mdepth; float* out_alpha; float* out_normal;
+  uint32_t* n_contrib; float* accum_coord; float* accum_depth; float* normal_length;
+};
+
+// blockIdx -> work item such that each XCD (block b runs on XCD b % 8) owns a contiguous band.
+__device__ __forceinline__ int xcd_band_remap(int b, int n) {
+  const int q = n >> 3, r = n & 7, xcd = b & 7, loc = b >> 3;
+  return xcd * q + (xcd < r ? xcd : r) + loc;
+}
+
+template <bool COORD, bool DEPTH, int PPL>
+__global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
+  constexpr bool NORMAL = COORD || DEPTH;
+  constexpr int WPT = 4 / PPL;  // waves per tile
+  __shared__ float4 lds_a[65 * 4];
+  __shared__ float4 lds_b[COORD ? 64 * 3 : 1];
+
+  const int item = xcd_band_remap(blockIdx.x, gridDim.x);
+  const int tile = item / WPT, sub = item - tile * WPT;
+  const int tile_x = tile % a.gx, tile_y = tile / a.gx;
+  const int lane = threadIdx.x, lx = lane & 15, lr = lane >> 4;
+  const int px = tile_x * 16 + lx;
+  const int py0 = tile_y * 16 + sub * (4 * PPL) + lr;  // slot s -> row py0 + 4*s
+  const int W = a.W, H = a.H;
+  const size_t HW = (size_t)H * W;
+  const float pixfx = (float)px;
+
+  const uint2 range = a.ranges[tile];
+  const int n = (int)(range.y - range.x);
+
+  float pixfy[PPL], T[PPL], Cr[PPL], Cg[PPL], Cb[PPL], weight[PPL];
+  float Dep[PPL], mDep[PPL], Nx[PPL], Ny[PPL], Nz[PPL];
+  float Co[COORD ? PPL : 1][3], mCo[COORD ? PPL : 1][3];
+  uint32_t last_c[PPL], max_c[PPL];
+  bool done[PPL], inside[PPL];
+#pragma unroll
+  for (int s = 0; s < PPL; s++) {
+    const int py = py0 + 4 * s;
+    pixfy[s] = (float)py;
+    inside[s] = px < W && py < H;
+    done[s] = !inside[s];
+    T[s] = 1.0f; Cr[s] = Cg[s] = Cb[s] = 0.f; weight[s] = 0.f;
+    Dep[s] = mDep[s] = 0.f; Nx[s] = Ny[s] = Nz[s] = 0.f;
+    last_c[s] = 0; max_c[s] = 0xFFFFFFFFu;
+    if constexpr (COORD) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) { Co[s][c] = 0.f; mCo[s][c] = 0.f; }
+    }
+  }
+  bool all_done;
+  {
+    bool d = true;
+#pragma unroll
+    for (int s = 0; s < PPL; s++) d = d && done[s];
+    all_done = __all(d);
+  }
+
+  for (int base = 0; base < n && !all_done; base += 64) {
+    // ---- stage up to 64 list entries: one 64-B record (one cache line) per lane ----
+    __syncthreads();
+    const int k = base + lane;
+    if (k < n) {
+      const uint32_t g = a.point_list[range.x + k];
+      const float4* src = a.splat_a + 4 * (size_t)g;
+      const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+      lds_a[lane * 4 + 0] = q0; lds_a[lane * 4 + 1] = q1; lds_a[lane * 4 + 2] = q2; lds_a[lane * 4 + 3] = q3;
+      if constexpr (COORD) {
+        const float4* sb = a.splat_b + 3 * (size_t)g;
+        lds_b[lane * 3 + 0] = sb[0]; lds_b[lane * 3 + 1] = sb[1]; lds_b[lane * 3 + 2] = sb[2];
+      }
+    }
+    __syncthreads();
+    const int cnt = min(64, n - base);
+    float4 nA = lds_a[0], nB = lds_a[1];
+    for (int j = 0; j < cnt; j++) {
+      const float4 A = nA, B = nB;         // {mx,my,cx,cy} {cz,op,thr,ts}
+      nA = lds_a[(j + 1) * 4 + 0];         // prefetch next entry (slot 64 is padding)
+      nB = lds_a[(j + 1) * 4 + 1];
+      const float dx = A.x - pixfx;
+      const float a_x = (A.z * dx) * dx;
+      const float b_xy = A.w * dx;
+      float power[PPL];
+      bool cand[PPL], anyc = false;
+#pragma unroll
+      for (int s = 0; s < PPL; s++) {
+        const float dy = A.y - pixfy[s];
+        power[s] = splat_power(a_x, b_xy, B.x, dy);
+        cand[s] = !done[s] && !(power[s] > 0.0f) && !(power[s] < B.z);
+        anyc = anyc || cand[s];
+      }
+      if (!__any(anyc)) continue;
+      const float4 C = lds_a[j * 4 + 2], Dq = lds_a[j * 4 + 3];  // {r,g,b,rpx} {rpy,nx,ny,nz}
+      float4 E0, E1, E2;
+      if constexpr (COORD) { E0 = lds_b[j * 3 + 0]; E1 = lds_b[j * 3 + 1]; E2 = lds_b[j * 3 + 2]; }
+      const uint32_t contributor = (uint32_t)(base + j + 1);
+      bool newly_done = false;
+#pragma unroll
+      for (int s = 0; s < PPL; s++) {
+        if (cand[s]) {
+          const float G = exp_spec(power[s]);
+          const float alpha = fminf(0.99f, B.y * G);
+          if (!(alpha < 1.0f / 255.0f)) {
+            const float test_T = T[s] * (1 - alpha);
+            if (test_T < 0.0001f) {
+              done[s] = true;
+              newly_done = true;
+            } else {
+              const float aT = alpha * T[s];
+              const float dy = A.y - pixfy[s];
+              Cr[s] = fmaf(C.x, aT, Cr[s]); Cg[s] = fmaf(C.y, aT, Cg[s]); Cb[s] = fmaf(C.z, aT, Cb[s]);
+              const bool before_median = T[s] > 0.5f;
+              if constexpr (COORD) {
+                const float c0 = fmaf(E0.y, dy, fmaf(E0.x, dx, E1.z));
+                const float c1 = fmaf(E0.w, dy, fmaf(E0.z, dx, E1.w));
+                const float c2 = fmaf(E1.y, dy, fmaf(E1.x, dx, E2.x));
+                Co[s][0] = fmaf(c0, aT, Co[s][0]); Co[s][1] = fmaf(c1, aT, Co[s][1]); Co[s][2] = fmaf(c2, aT, Co[s][2]);
+                if (before_median) { mCo[s][0] = c0; mCo[s][1] = c1; mCo[s][2] = c2; }
+              }
+              if constexpr (DEPTH) {
+                const float t = B.w + fmaf(C.w, dx, Dq.x * dy);
+                Dep[s] = fmaf(t, aT, Dep[s]);
+                if (before_median) mDep[s] = t;
+              }
+              if constexpr (NORMAL) {
+                Nx[s] = fmaf(Dq.y, aT, Nx[s]); Ny[s] = fmaf(Dq.z, aT, Ny[s]); Nz[s] = fmaf(Dq.w, aT, Nz[s]);
+                if (before_median) max_c[s] = contributor;
+              }
+              weight[s] += aT;
+              T[s] = test_T;
+              last_c[s] = contributor;
+            }
+          }
+        }
+      }
+      if (__any(newly_done)) {
+        bool d = true;
+#pragma unroll
+        for (int s = 0; s < PPL; s++) d = d && done[s];
+        all_done = __all(d);
+        if (all_done) break;
+      }
+    }
+  }
+
+  // ---- epilogue (forward.cu:631-692) ----
+  const float pnx = (pixfx - W / 2.f) / a.focal_x;
+#pragma unroll
+  for (int s = 0; s < PPL; s++) {
+    if (!inside[s]) continue;
+    const size_t pix = (size_t)W * (py0 + 4 * s) + px;
+    const float pny = (pixfy[s] - H / 2.f) / a.focal_y;
+    const float ln = sqrtf(pnx * pnx + pny * pny + 1);
+    a.n_contrib[pix] = last_c[s];
+    a.n_contrib[pix + HW] = max_c[s];
+    a.out_color[pix] = fmaf(T[s], a.bg[0], Cr[s]);
+    a.out_color[HW + pix] = fmaf(T[s], a.bg[1], Cg[s]);
+    a.out_color[2 * HW + pix] = fmaf(T[s], a.bg[2], Cb[s]);
+    a.out_alpha[pix] = weight[s];
+    if constexpr (COORD) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        a.out_coord[c * HW + pix] = last_c[s] ? Co[s][c] / weight[s] : 0.f;
+        a.accum_coord[c * HW + pix] = Co[s][c];
+        a.out_mcoord[c * HW + pix] = mCo[s][c];
+      }
+    }
+    if constexpr (DEPTH) {
+      const float depth_ln = Dep[s] / ln;
+      a.accum_depth[pix] = depth_ln;
+      a.out_depth[pix] = last_c[s] ? depth_ln / weight[s] : 0.f;
+      a.out_mdepth[pix] = mDep[s] / ln;
+    }
+    if constexpr (NORMAL) {
+      if (last_c[s]) {
+        float len_n = sqrtf(Nx[s] * Nx[s] + Ny[s] * Ny[s] + Nz[s] * Nz[s]);
+        a.normal_length[pix] = len_n;
+        len_n = fmaxf(len_n, 1.0E-12F);
+        a.out_normal[pix] = Nx[s] / len_n;
+        a.out_normal[HW + pix] = Ny[s] / len_n;
+        a.out_normal[2 * HW + pix] = Nz[s] / len_n;
+      } else {
+        a.normal_length[pix] = 1;
+        a.out_normal[pix] = 0; a.out_normal[HW + pix] = 0; a.out_normal[2 * HW + pix] = 0;
+      }
+    }
+  }
+}
+
+// =========================================================================== blend, bwd ==
+struct BlendBwdArgs {
+  const uint2* ranges; const uint32_t* point_list; const float4* splat_a; const float4* splat_b;
+  int W, H, gx, ntiles; float focal_x, focal_y;
+  const float* bg;
+  const float* alphas; const float* normalmap;
+  const uint32_t* n_contrib; const float* accum_coord; const float* accum_depth; const float* normal_length;
+  const float* dL_dpix; const float* dL_dcoord; const float* dL_dmcoord; const float* dL_ddepth; const float* dL_dmdepth;
+  const float* dL_dalpha; const float* dL_dnormal;
+  float* acc;  // [P][REC] per-Gaussian sums, SplatAcc order
+};
+
+// In: v[i] = this lane's partial sum of component i.  Out (return value): the wave-wide total of
+// component (lane & (N-1)).  log2(N) butterfly stages halve the live components while doubling
+// the lanes summed; the remaining lane bits are folded with plain xor exchanges.
+template <int N>
+__device__ __forceinline__ float wave_reduce_scatter(float (&v)[N], int lane) {
+  int half = N / 2;
+#pragma unroll
+  for (int bit = (N == 32 ? 4 : 3); bit >= 0; --bit) {
+    const bool up = (lane >> bit) & 1;
+#pragma unroll
+    for (int i = 0; i < N / 2; i++) {
+      if (i < half) {
+        const float send = up ? v[i] : v[i + half];
+        const float keep = up ? v[i + half] : v[i];
+        v[i] = keep + __shfl_xor(send, 1 << bit);
+      }
+    }
+    half >>= 1;
+  }
+  float r = v[0];
+  if (N == 16) r += __shfl_xor(r, 16);
+  r += __shfl_xor(r, 32);
+  return r;
+}
+
+template <bool COORD, bool DEPTH, int PPL>
+__global__ void __launch_bounds__(64) blend_bwd_kernel(const BlendBwdArgs a) {
+  constexpr bool NORMAL = COORD || DEPTH;
+  constexpr int WPT = 4 / PPL;
+  constexpr int REC = COORD ? 32 : 16;
+  __shared__ float4 lds_a[65 * 4];
+  __shared__ float4 lds_b[COORD ? 64 * 3 : 1];
+  __shared__ uint32_t lds_id[64];
+
+  const int item = xcd_band_remap(blockIdx.x, gridDim.x);
+  const int tile = item / WPT, sub = item - tile * WPT;
+  const int tile_x = tile % a.gx, tile_y = tile / a.gx;
+  const int lane = threadIdx.x, lx = lane & 15, lr = lane >> 4;
+  const int px = tile_x * 16 + lx;
+  const int py0 = tile_y * 16 + sub * (4 * PPL) + lr;
+  const int W = a.W, H = a.H;
+  const size_t HW = (size_t)H * W;
+  const float pixfx = (float)px;
+  const uint2 range = a.ranges[tile];
+
+  // ---- per-pixel prologue (backward.cu:706-781) ----
+  float pixfy[PPL], T[PPL], T_final[PPL], last_alpha[PPL], acc_a[PPL], dLa[PPL], bgdot[PPL];
+  float dLc[PPL][3], accC[PPL][3], lastC[PPL][3];
+  float dLt[PPL], dLmt[PPL], accT[PPL], lastT[PPL];
+  float dLn[PPL][3], accN[PPL][3], lastN[PPL][3];
+  float dLco[COORD ? PPL : 1][3], dLmco[COORD ? PPL : 1][3], accCo[COORD ? PPL : 1][3], lastCo[COORD ? PPL : 1][3];
+  uint32_t last_c[PPL], max_cm1[PPL];
+  uint32_t wave_last = 0;
+  const float pnx = (pixfx - W / 2.f) / a.focal_x;
+#pragma unroll
+  for (int s = 0; s < PPL; s++) {
+    const int py = py0 + 4 * s;
+    pixfy[s] = (float)py;
+    const bool inside = px < W && py < H;
+    const size_t pix = inside ? (size_t)W * py + px : 0;
+    const float alpha_px = inside ? a.alphas[pix] : 0.f;
+    T_final[s] = inside ? (1 - alpha_px) : 0.f;
+    const float w_final = alpha_px;
+    T[s] = T_final[s];
+    last_c[s] = inside ? a.n_contrib[pix] : 0u;
+    max_cm1[s] = (inside ? a.n_contrib[pix + HW] : 0u) - 1u;  // compared against the 0-based position
+    wave_last = max(wave_last, last_c[s]);
+    last_alpha[s] = 0.f; acc_a[s] = 0.f;
+    dLt[s] = dLmt[s] = 0.f; accT[s] = lastT[s] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      dLc[s][c] = inside ? a.dL_dpix[c * HW + pix] : 0.f;
+      accC[s][c] = lastC[s][c] = 0.f;
+      dLn[s][c] = 0.f; accN[s][c] = lastN[s][c] = 0.f;
+      if constexpr (COORD) { dLco[s][c] = dLmco[s][c] = 0.f; accCo[s][c] = lastCo[s][c] = 0.f; }
+    }
+    dLa[s] = inside ? a.dL_dalpha[pix] : 0.f;
+    bgdot[s] = a.bg[0] * dLc[s][0] + a.bg[1] * dLc[s][1] + a.bg[2] * dLc[s][2];
+    if (NORMAL && inside) {
+      const float ww = w_final * w_final;
+      const float pny = (pixfy[s] - H / 2.f) / a.focal_y;
+      const float ln = sqrtf(pnx * pnx + pny * pny + 1);
+      if constexpr (COORD) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const float gw = a.dL_dcoord[c * HW + pix];
+          dLa[s] -= gw * a.accum_coord[c * HW + pix] / ww;
+          dLco[s][c] = gw / w_final;
+          dLmco[s][c] = a.dL_dmcoord[c * HW + pix];
+        }
+      }
+      if constexpr (DEPTH) {
+        const float gw = a.dL_ddepth[pix];
+        dLa[s] -= gw * a.accum_depth[pix] / ww;
+        dLt[s] = gw / w_final / ln;
+        dLmt[s] = a.dL_dmdepth[pix] / ln;
+      }
+      {
+        const float g0 = a.dL_dnormal[pix], g1 = a.dL_dnormal[HW + pix], g2 = a.dL_dnormal[2 * HW + pix];
+        const float n0 = a.normalmap[pix], n1 = a.normalmap[HW + pix], n2 = a.normalmap[2 * HW + pix];
+        const float nlen = a.normal_length[pix];
+        if (nlen < 1.0E-12F) {
+          dLn[s][0] = g0 / 1.0E-12F; dLn[s][1] = g1 / 1.0E-12F; dLn[s][2] = g2 / 1.0E-12F;
+        } else {
+          const float dt = g0 * n0 + g1 * n1 + g2 * n2;
+          dLn[s][0] = (g0 - dt * n0) / nlen; dLn[s][1] = (g1 - dt * n1) / nlen; dLn[s][2] = (g2 - dt * n2) / nlen;
+        }
+      }
+    }
+  }
+  // entries at or beyond the furthest last contributor of this strip contribute to no pixel
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, m));
+  const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+  const float inv_fx = 1.0f / a.focal_x, inv_fy = 1.0f / a.focal_y;
+
+  for (int hi = (int)wave_last; hi > 0; hi -= 64) {
+    __syncthreads();
+    const int e = hi - 1 - lane;
+    if (e >= 0) {
+      const uint32_t g = a.point_list[range.x + e];
+      lds_id[lane] = g;
+      const float4* src = a.splat_a + 4 * (size_t)g;
+      const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+      lds_a[lane * 4 + 0] = q0; lds_a[lane * 4 + 1] = q1; lds_a[lane * 4 + 2] = q2; lds_a[lane * 4 + 3] = q3;
+      if constexpr (COORD) {
+        const float4* sb = a.splat_b + 3 * (size_t)g;
+        lds_b[lane * 3 + 0] = sb[0]; lds_b[lane * 3 + 1] = sb[1]; lds_b[lane * 3 + 2] = sb[2];
+      }
+    }
+    __syncthreads();
+    const int cnt = min(64, hi);
+    float4 nA = lds_a[0], nB = lds_a[1];
+    for (int j = 0; j < cnt; j++) {
+      const float4 A = nA, B = nB;
+      nA = lds_a[(j + 1) * 4 + 0];
+      nB = lds_a[(j + 1) * 4 + 1];
+      const uint32_t pos = (uint32_t)(hi - 1 - j);  // 0-based list position == `contributor`
+      const float dx = A.x - pixfx;
+      const float a_x = (A.z * dx) * dx;
+      const float b_xy = A.w * dx;
+      float power[PPL];
+      bool cand[PPL], anyc = false;
+#pragma unroll
+      for (int s = 0; s < PPL; s++) {
+        const float dy = A.y - pixfy[s];
+        power[s] = splat_power(a_x, b_xy, B.x, dy);
+        cand[s] = (pos < last_c[s]) && !(power[s] > 0.0f) && !(power[s] < B.z);
+        anyc = anyc || cand[s];
+      }
+      if (!__any(anyc)) continue;
+      const float4 C = lds_a[j * 4 + 2], Dq = lds_a[j * 4 + 3];
+      float4 E0, E1, E2;
+      if constexpr (COORD) { E0 = lds_b[j * 3 + 0]; E1 = lds_b[j * 3 + 1]; E2 = lds_b[j * 3 + 2]; }
+      float gv[REC];
+#pragma unroll
+      for (int i = 0; i < REC; i++) gv[i] = 0.f;
+      bool contributed = false;
+#pragma unroll
+      for (int s = 0; s < PPL; s++) {
+        if (cand[s]) {
+          const float G = exp_spec(power[s]);
+          const float alpha = fminf(0.99f, B.y * G);
+          if (!(alpha < 1.0f / 255.0f)) {
+            contributed = true;
+            const float dy = A.y - pixfy[s];
+            const float one_m_a = 1.f - alpha;
+            const float inv1ma = 1.0f / one_m_a;
+            T[s] = T[s] * inv1ma;
+            const float dch = alpha * T[s];
+            const float la = last_alpha[s], one_m_la = 1.f - la;
+            float dL_dopa = 0.f;
+            {
+              const float col[3] = {C.x, C.y, C.z};
+#pragma unroll
+              for (int c = 0; c < 3; c++) {
+                accC[s][c] = fmaf(la, lastC[s][c], one_m_la * accC[s][c]);
+                lastC[s][c] = col[c];
+                dL_dopa = fmaf(col[c] - accC[s][c], dLc[s][c], dL_dopa);
+                gv[c] = fmaf(dch, dLc[s][c], gv[c]);
+              }
+            }
+            float dco[3] = {0.f, 0.f, 0.f}, dt_ = 0.f;
+            const bool is_median = pos == max_cm1[s];
+            if constexpr (COORD) {
+              const float cpx[3] = {E0.x, E0.z, E1.x}, cpy[3] = {E0.y, E0.w, E1.y}, vp[3] = {E1.z, E1.w, E2.x};
+#pragma unroll
+              for (int c = 0; c < 3; c++) {
+                const float cc = fmaf(cpy[c], dy, fmaf(cpx[c], dx, vp[c]));
+                accCo[s][c] = fmaf(la, lastCo[s][c], one_m_la * accCo[s][c]);
+                lastCo[s][c] = cc;
+                dL_dopa = fmaf(cc - accCo[s][c], dLco[s][c], dL_dopa);
+                dco[c] = dch * dLco[s][c];
+                if (is_median) dco[c] += dLmco[s][c];
+                gv[16 + c] += dco[c];
+                gv[19 + 2 * c] = fmaf(dco[c] * dx, inv_fx, gv[19 + 2 * c]);
+                gv[20 + 2 * c] = fmaf(dco[c] * dy, inv_fy, gv[20 + 2 * c]);
+              }
+            }
+            if constexpr (DEPTH) {
+              const float t = B.w + fmaf(C.w, dx, Dq.x * dy);
+              accT[s] = fmaf(la, lastT[s], one_m_la * accT[s]);
+              lastT[s] = t;
+              dL_dopa = fmaf(t - accT[s], dLt[s], dL_dopa);
+              dt_ = dch * dLt[s];
+              if (is_median) dt_ += dLmt[s];
+              gv[3] += dt_;
+              gv[4] = fmaf(dt_ * dx, inv_fx, gv[4]);
+              gv[5] = fmaf(dt_ * dy, inv_fy, gv[5]);
+            }
+            if constexpr (NORMAL) {
+              const float nn[3] = {Dq.y, Dq.z, Dq.w};
+#pragma unroll
+              for (int c = 0; c < 3; c++) {
+                accN[s][c] = fmaf(la, lastN[s][c], one_m_la * accN[s][c]);
+                lastN[s][c] = nn[c];
+                dL_dopa = fmaf(nn[c] - accN[s][c], dLn[s][c], dL_dopa);
+                gv[6 + c] = fmaf(dch, dLn[s][c], gv[6 + c]);
+              }
+            }
+            acc_a[s] = fmaf(one_m_la, acc_a[s], la);
+            dL_dopa = fmaf(1 - acc_a[s], dLa[s], dL_dopa);
+            dL_dopa *= T[s];
+            last_alpha[s] = alpha;
+            dL_dopa = fmaf(-T_final[s] * inv1ma, bgdot[s], dL_dopa);
+
+            const float dL_dG = B.y * dL_dopa;
+            const float gdx = G * dx, gdy = G * dy;
+            const float dG_ddelx = -gdx * A.z - gdy * A.w;
+            const float dG_ddely = -gdy * B.x - gdx * A.w;
+            const float gx_ = dL_dG * dG_ddelx, gy_ = dL_dG * dG_ddely;
+            float dL_ddelx = gx_, dL_ddely = gy_;
+            if constexpr (COORD) {
+              dL_ddelx += dco[0] * E0.x + dco[1] * E0.z + dco[2] * E1.x;
+              dL_ddely += dco[0] * E0.y + dco[1] * E0.w + dco[2] * E1.y;
+            }
+            if constexpr (DEPTH) {
+              dL_ddelx = fmaf(dt_, C.w, dL_ddelx);
+              dL_ddely = fmaf(dt_, Dq.x, dL_ddely);
+            }
+            gv[9] = fmaf(dL_ddelx, ddelx_dx, gv[9]);
+            gv[10] = fmaf(dL_ddely, ddely_dy, gv[10]);
+            gv[11] += fabsf(gx_ * ddelx_dx) + fabsf(gy_ * ddely_dy);
+            gv[12] = fmaf(-0.5f * gdx * dx, dL_dG, gv[12]);
+            gv[13] = fmaf(-0.5f * gdx * dy, dL_dG, gv[13]);
+            gv[14] = fmaf(-0.5f * gdy * dy, dL_dG, gv[14]);
+            gv[15] = fmaf(G, dL_dopa, gv[15]);
+          }
+        }
+      }
+      if (!__any(contributed)) continue;
+      const float tot = wave_reduce_scatter<REC>(gv, lane);
+      if (lane < (COORD ? 25 : 16)) unsafeAtomicAdd(a.acc + (size_t)lds_id[j] * REC + lane, tot);
+    }
+  }
+}
+
+// ======================================================================= preprocess, bwd ==
+struct PreBwdArgs {
+  int P, D, M;
+  const float* means3D; const float* scales; const float* rotations; const float* cov3D_precomp; const float* shs;
+  const int* radii; const float4* splat_a; const uint8_t* clamped; const float* acc; int rec;
+  CamArgs cam;
+  float* dL_dmean2D; float* dL_dcolor; float* dL_dopacity; float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale;
+  float* dL_drot;
+};
+
+__global__ void __launch_bounds__(256) preprocess_bwd_kernel(const PreBwdArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.P) return;
+  const size_t i = (size_t)idx;
+  float* dsh = a.dL_dsh ? a.dL_dsh + i * a.M * 3 : nullptr;
+  if (!(a.radii[idx] > 0)) {  // invisible: every returned row is zero (rasterize_points.cu:180-193)
+    for (int c = 0; c < 3; c++) { a.dL_dmean2D[3 * i + c] = 0; a.dL_dcolor[3 * i + c] = 0; a.dL_dmean3D[3 * i + c] = 0; a.dL_dscale[3 * i + c] = 0; }
+    a.dL_dopacity[i] = 0;
+    for (int c = 0; c < 6; c++) a.dL_dcov3D[6 * i + c] = 0;
+    for (int c = 0; c < 4; c++) a.dL_drot[4 * i + c] = 0;
+    if (dsh) for (int c = 0; c < a.M * 3; c++) dsh[c] = 0;
+    return;
+  }
+  const Camera cam = load_camera(a.cam);
+  SplatAcc acc;
+  {
+    const float* r = a.acc + i * a.rec;
+    float* dst = reinterpret_cast<float*>(&acc);
+#pragma unroll
+    for (int c = 0; c < 16; c++) dst[c] = r[c];
+    if (a.rec == 32) {
+#pragma unroll
+      for (int c = 16; c < 25; c++) dst[c] = r[c];
+    } else {
+#pragma unroll
+      for (int c = 16; c < 25; c++) dst[c] = 0.f;
+    }
+  }
+  const float* m = a.means3D + 3 * i;
+  const float* sc = a.scales ? a.scales + 3 * i : nullptr;
+  const float* rq = a.rotations ? a.rotations + 4 * i : nullptr;
+  float cov[6];
+  if (a.cov3D_precomp) {
+#pragma unroll
+    for (int c = 0; c < 6; c++) cov[c] = a.cov3D_precomp[6 * i + c];
+  } else {
+    cov3d_from_scale_rot(sc, cam.scale_modifier, rq, cov);
+  }
+  const float op_combined = a.splat_a[4 * i + 1].y;
+  const float* sh = a.shs ? a.shs + i * a.M * 3 : nullptr;
+  if (dsh) {  // rows beyond the active degree stay zero
+    const int K = (a.D + 1) * (a.D + 1);
+    for (int c = K * 3; c < a.M * 3; c++) dsh[c] = 0;
+  }
+  SplatBwd o;
+  o.dscale[0] = o.dscale[1] = o.dscale[2] = 0; o.drot[0] = o.drot[1] = o.drot[2] = o.drot[3] = 0;
+  preprocess_bwd(mk3(m[0], m[1], m[2]), sc, rq, cov, op_combined, a.D, sh, (unsigned)a.clamped[idx], cam, acc, dsh, o);
+  for (int c = 0; c < 3; c++) {
+    a.dL_dmean2D[3 * i + c] = acc.dmean2D[c];
+    a.dL_dcolor[3 * i + c] = acc.dcolor[c];
+    a.dL_dmean3D[3 * i + c] = o.dmean3D[c];
+    a.dL_dscale[3 * i + c] = o.dscale[c];
+  }
+  a.dL_dopacity[i] = o.dopacity;
+  for (int c = 0; c < 6; c++) a.dL_dcov3D[6 * i + c] = o.dcov3D[c];
+  for (int c = 0; c < 4; c++) a.dL_drot[4 * i + c] = o.drot[c];
+}
+
+}  // namespace rg
+
+// The host-side orchestration (C ABI) lives in radegs_api.hip, which includes this file's
+// declarations through rg_launch.h.
+#include "rg_launch.inc"

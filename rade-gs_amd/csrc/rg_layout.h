@@ -1,0 +1,123 @@
+// rg_layout.h -- private layout of the three state buffers (geometry / binning / image) and of
+// the per-Gaussian gradient accumulator.  The reference carves SoA arrays out of opaque byte
+// buffers (DGR/cuda_rasterizer/rasterizer_impl.cu:190-250, rasterizer_impl.h:29-94); the layout
+// is private to forward/backward there too (Python only sees uint8 tensors), so it is redesigned
+// here for how gfx950 actually reads it:
+//
+//   * splat_a  [P][16] f32, one 64-byte record per Gaussian = everything the blend loops gather
+//              for one list entry in depth mode, fetched as 4 x dwordx4 from ONE cache line:
+//                 { mx, my, cx, cy | cz, op, thr, ts | r, g, b, rpx | rpy, nx, ny, nz }
+//              (mx,my pixel centre; c* conic; op = opacity*coef; thr = conservative skip
+//              threshold on the exponent; ts = |p_view|; rp = ray-space depth plane; n = normal)
+//   * splat_b  [P][12] f32 (48 B), only when the coord map is requested:
+//                 { cp0..cp3 | cp4, cp5, vpx, vpy | vpz, 0, 0, 0 }
+//   * depth_key/tiles_touched/clamped: per-Gaussian scalars for binning and the backward
+//   * the reference's cov3D array is not stored at all: the backward re-derives it from
+//     scale/rotation with the same code (bit-identical), saving 48 B/Gaussian of traffic.
+//
+// Binning: Gaussians are radix-sorted ONCE by depth (P 32-bit keys), instances are emitted in
+// that order with the tile id as key, and a stable sort on the `bit` tile bits finishes the job.
+// The result is the same (tile, depth, index) order a stable 64-bit [tile|depth] sort gives
+// (rasterizer_impl.cu:70-111,373-381), at ~1/4 of the sort traffic.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace rg {
+
+constexpr size_t kAlign = 256;
+inline size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
+
+struct Carver {
+  char* base;
+  size_t off;
+  explicit Carver(void* b) : base(static_cast<char*>(b)), off(0) {}
+  template <class T> T* take(size_t count) {
+    off = align_up(off);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+  size_t total() const { return align_up(off) + kAlign; }
+};
+
+struct GeomState {
+  float* splat_a;          // [P*16]
+  float* splat_b;          // [P*12] (coord only)
+  uint32_t* tiles_touched; // [P]
+  uint32_t* depth_key;     // [P]
+  uint8_t* clamped;        // [P]
+  // forward-only scratch
+  uint32_t* depth_key_sorted;  // [P]
+  uint32_t* idx_sorted;        // [P]
+  uint32_t* offsets;           // [P] inclusive scan of tiles_touched in depth order
+  char* temp;                  // device-primitive temp storage
+  size_t temp_bytes;
+  size_t total;
+  static GeomState carve(void* buf, size_t P, bool coord, size_t temp_bytes) {
+    Carver c(buf);
+    GeomState g;
+    g.splat_a = c.take<float>(P * 16);
+    g.splat_b = c.take<float>(coord ? P * 12 : 0);
+    g.tiles_touched = c.take<uint32_t>(P);
+    g.depth_key = c.take<uint32_t>(P);
+    g.clamped = c.take<uint8_t>(P);
+    g.depth_key_sorted = c.take<uint32_t>(P);
+    g.idx_sorted = c.take<uint32_t>(P);
+    g.offsets = c.take<uint32_t>(P);
+    g.temp = c.take<char>(temp_bytes);
+    g.temp_bytes = temp_bytes;
+    g.total = c.total();
+    return g;
+  }
+};
+
+struct BinState {
+  uint32_t* point_list;        // [R] sorted Gaussian indices (kept for the backward)
+  uint32_t* tile_keys_sorted;  // [R]
+  uint32_t* tile_keys;         // [R] unsorted
+  uint32_t* point_list_unsorted;  // [R]
+  char* temp;
+  size_t temp_bytes;
+  size_t total;
+  static BinState carve(void* buf, size_t R, size_t temp_bytes) {
+    Carver c(buf);
+    BinState b;
+    b.point_list = c.take<uint32_t>(R);
+    b.tile_keys_sorted = c.take<uint32_t>(R);
+    b.tile_keys = c.take<uint32_t>(R);
+    b.point_list_unsorted = c.take<uint32_t>(R);
+    b.temp = c.take<char>(temp_bytes);
+    b.temp_bytes = temp_bytes;
+    b.total = c.total();
+    return b;
+  }
+};
+
+struct ImageState {
+  uint32_t* ranges;      // [2*tiles]  (start,end) per tile
+  uint32_t* n_contrib;   // [2*H*W]    plane 0: last contributor, plane 1: last contributor with T>0.5
+  float* accum_coord;    // [3*H*W]
+  float* accum_depth;    // [H*W]
+  float* normal_length;  // [H*W]
+  size_t total;
+  static ImageState carve(void* buf, size_t W, size_t H) {
+    Carver c(buf);
+    ImageState s;
+    const size_t tiles = ((W + 15) / 16) * ((H + 15) / 16), N = W * H;
+    s.ranges = c.take<uint32_t>(2 * tiles);
+    s.n_contrib = c.take<uint32_t>(2 * N);
+    s.accum_coord = c.take<float>(3 * N);
+    s.accum_depth = c.take<float>(N);
+    s.normal_length = c.take<float>(N);
+    s.total = c.total();
+    return s;
+  }
+};
+
+// Per-Gaussian gradient accumulator record written by the blend backward with one 16/25-lane
+// atomic instruction: floats in rg::SplatAcc order; 16 per Gaussian without the coord map
+// (64 B = one line), 32 with it.
+inline int acc_record_floats(bool coord) { return coord ? 32 : 16; }
+
+}  // namespace rg

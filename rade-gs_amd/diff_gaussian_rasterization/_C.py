@@ -1,0 +1,273 @@
+"""`_C` -- binding of libradegs_hip.so (C ABI: include/radegs.h) with the call surface of the
+reference's pybind module (DGR/ext.cpp:15-19):
+
+    rasterize_gaussians(...)            DGR/rasterize_points.h:18-42  / rasterize_points.cu:36-133
+    rasterize_gaussians_backward(...)   DGR/rasterize_points.h:43-76  / rasterize_points.cu:136-246
+    mark_visible(...)                   DGR/rasterize_points.h:78-81  / rasterize_points.cu:248-267
+
+Same positional arguments, same return tuples (note the forward's output order differs from the
+Python operator's 8-tuple, exactly as upstream).  torch is used for device memory and the current
+HIP stream only; no torch type crosses the C boundary.
+
+There is NO CPU path and no fallback: a missing library or a non-GPU tensor raises.
+`integrate_gaussians_to_points` (marching-tetrahedra extraction) is not built yet and
+raises NotImplementedError.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libradegs_hip.so")
+
+_ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+_F = ctypes.POINTER(ctypes.c_float)
+
+
+class RadegsFwdArgs(ctypes.Structure):
+    _fields_ = [("P", ctypes.c_int), ("D", ctypes.c_int), ("M", ctypes.c_int), ("width", ctypes.c_int), ("height", ctypes.c_int),
+                ("background", ctypes.c_void_p), ("means3D", ctypes.c_void_p), ("shs", ctypes.c_void_p),
+                ("colors_precomp", ctypes.c_void_p), ("opacities", ctypes.c_void_p), ("scales", ctypes.c_void_p),
+                ("rotations", ctypes.c_void_p), ("cov3D_precomp", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p),
+                ("projmatrix", ctypes.c_void_p), ("cam_pos", ctypes.c_void_p),
+                ("scale_modifier", ctypes.c_float), ("tan_fovx", ctypes.c_float), ("tan_fovy", ctypes.c_float),
+                ("kernel_size", ctypes.c_float),
+                ("prefiltered", ctypes.c_int), ("require_coord", ctypes.c_int), ("require_depth", ctypes.c_int), ("debug", ctypes.c_int),
+                ("out_color", ctypes.c_void_p), ("out_coord", ctypes.c_void_p), ("out_mcoord", ctypes.c_void_p),
+                ("out_depth", ctypes.c_void_p), ("out_mdepth", ctypes.c_void_p), ("out_alpha", ctypes.c_void_p),
+                ("out_normal", ctypes.c_void_p), ("radii", ctypes.c_void_p)]
+
+
+class RadegsBwdArgs(ctypes.Structure):
+    _fields_ = [("P", ctypes.c_int), ("D", ctypes.c_int), ("M", ctypes.c_int), ("R", ctypes.c_int), ("width", ctypes.c_int),
+                ("height", ctypes.c_int),
+                ("background", ctypes.c_void_p), ("means3D", ctypes.c_void_p), ("shs", ctypes.c_void_p),
+                ("colors_precomp", ctypes.c_void_p), ("alphas", ctypes.c_void_p), ("scales", ctypes.c_void_p),
+                ("rotations", ctypes.c_void_p), ("cov3D_precomp", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p),
+                ("projmatrix", ctypes.c_void_p), ("cam_pos", ctypes.c_void_p),
+                ("scale_modifier", ctypes.c_float), ("tan_fovx", ctypes.c_float), ("tan_fovy", ctypes.c_float),
+                ("kernel_size", ctypes.c_float),
+                ("radii", ctypes.c_void_p), ("normalmap", ctypes.c_void_p), ("geom_buffer", ctypes.c_void_p),
+                ("binning_buffer", ctypes.c_void_p), ("image_buffer", ctypes.c_void_p),
+                ("dL_dpix", ctypes.c_void_p), ("dL_dpix_coord", ctypes.c_void_p), ("dL_dpix_mcoord", ctypes.c_void_p),
+                ("dL_dpix_depth", ctypes.c_void_p), ("dL_dpix_mdepth", ctypes.c_void_p), ("dL_dalphas", ctypes.c_void_p),
+                ("dL_dpix_normal", ctypes.c_void_p),
+                ("dL_dmean2D", ctypes.c_void_p), ("dL_dcolor", ctypes.c_void_p), ("dL_dopacity", ctypes.c_void_p),
+                ("dL_dmean3D", ctypes.c_void_p), ("dL_dcov3D", ctypes.c_void_p), ("dL_dsh", ctypes.c_void_p),
+                ("dL_dscale", ctypes.c_void_p), ("dL_drot", ctypes.c_void_p),
+                ("require_coord", ctypes.c_int), ("require_depth", ctypes.c_int), ("debug", ctypes.c_int)]
+
+
+# every symbol include/radegs.h declares
+EXPORTED_SYMBOLS = ("radegs_forward", "radegs_backward", "radegs_mark_visible", "radegs_geometry_bytes", "radegs_image_bytes",
+                    "radegs_binning_bytes", "radegs_debug_export", "radegs_last_error", "radegs_version")
+
+_lib = None
+
+
+def library():
+    """Load libradegs_hip.so (built in-tree by rade-gs_amd/build.py).  Fails loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} is missing: build it with `python rade-gs_amd/build.py` "
+                               "(there is no CPU or PyTorch fallback for this operator)")
+        L = ctypes.CDLL(_LIB_PATH)
+        L.radegs_forward.restype = ctypes.c_int
+        L.radegs_forward.argtypes = [ctypes.POINTER(RadegsFwdArgs), _ALLOC_FN, ctypes.c_void_p, _ALLOC_FN, ctypes.c_void_p, _ALLOC_FN,
+                                     ctypes.c_void_p, ctypes.c_void_p]
+        L.radegs_backward.restype = ctypes.c_int
+        L.radegs_backward.argtypes = [ctypes.POINTER(RadegsBwdArgs), _ALLOC_FN, ctypes.c_void_p, ctypes.c_void_p]
+        L.radegs_mark_visible.restype = ctypes.c_int
+        L.radegs_mark_visible.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.radegs_geometry_bytes.restype = ctypes.c_size_t
+        L.radegs_geometry_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.radegs_image_bytes.restype = ctypes.c_size_t
+        L.radegs_image_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.radegs_binning_bytes.restype = ctypes.c_size_t
+        L.radegs_binning_bytes.argtypes = [ctypes.c_int]
+        L.radegs_debug_export.restype = ctypes.c_longlong
+        L.radegs_debug_export.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.radegs_last_error.restype = ctypes.c_char_p
+        L.radegs_version.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise RuntimeError(f"{what} failed ({rc}): {library().radegs_last_error().decode()}")
+    return rc
+
+
+def _require_gpu(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"diff_gaussian_rasterization (MI355X build): `{name}` must be a GPU tensor -- "
+                           "this operator has no CPU implementation")
+
+
+def _f32(t, name):
+    """contiguous float32 view of an input; empty tensor == 'not provided' == NULL (reference convention)."""
+    if t is None or t.numel() == 0:
+        return None
+    _require_gpu(t, name)
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"`{name}` must be float32")
+    return t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class _Resizable:
+    """uint8 device tensor grown on request from the native side (the resize lambda of
+    DGR/rasterize_points.cu:27-33)."""
+
+    def __init__(self, device):
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.error = None
+
+        def _cb(_user, nbytes):
+            try:
+                self.tensor.resize_(int(nbytes))
+                return self.tensor.data_ptr()
+            except Exception as ex:  # surfaces as RADEGS_ERR_ALLOC
+                self.error = ex
+                return 0
+
+        self.cb = _ALLOC_FN(_cb)
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                        projmatrix, tan_fovx, tan_fovy, kernel_size, image_height, image_width, sh, degree, campos, prefiltered,
+                        require_coord, require_depth, debug):
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:60-62
+    _require_gpu(means3D, "means3D")
+    L = library()
+    dev = means3D.device
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    require_coord, require_depth = bool(require_coord), bool(require_depth)
+    fo = dict(dtype=torch.float32, device=dev)
+    live = P != 0
+
+    def out(c, written):
+        return torch.empty((c, H, W), **fo) if (live and written) else torch.zeros((c, H, W), **fo)
+
+    geo = require_coord or require_depth
+    out_color = out(3, True)
+    out_depth, out_mdepth = out(1, require_depth), out(1, require_depth)
+    out_coord, out_mcoord = out(3, require_coord), out(3, require_coord)
+    out_alpha = out(1, True)
+    out_normal = out(3, geo)
+    radii = torch.empty(P, dtype=torch.int32, device=dev) if live else torch.zeros(P, dtype=torch.int32, device=dev)
+    geom, binning, img = _Resizable(dev), _Resizable(dev), _Resizable(dev)
+    rendered = 0
+    if live:
+        bg, m3 = _f32(background, "bg"), _f32(means3D, "means3D")
+        col, op = _f32(colors, "colors_precomp"), _f32(opacity, "opacities")
+        sc, rot, cov = _f32(scales, "scales"), _f32(rotations, "rotations"), _f32(cov3D_precomp, "cov3D_precomp")
+        vm, pm, cp, shs = _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix"), _f32(campos, "campos"), _f32(sh, "shs")
+        M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
+        a = RadegsFwdArgs(P, int(degree), M, W, H, _ptr(bg), _ptr(m3), _ptr(shs), _ptr(col), _ptr(op), _ptr(sc), _ptr(rot), _ptr(cov),
+                          _ptr(vm), _ptr(pm), _ptr(cp), float(scale_modifier), float(tan_fovx), float(tan_fovy), float(kernel_size),
+                          int(bool(prefiltered)), int(require_coord), int(require_depth), int(bool(debug)),
+                          _ptr(out_color), _ptr(out_coord), _ptr(out_mcoord), _ptr(out_depth), _ptr(out_mdepth), _ptr(out_alpha),
+                          _ptr(out_normal), _ptr(radii))
+        with torch.cuda.device(dev):
+            rc = L.radegs_forward(ctypes.byref(a), geom.cb, None, binning.cb, None, img.cb, None, _stream(dev))
+        for r in (geom, binning, img):
+            if r.error is not None:
+                raise r.error
+        rendered = _check(rc, "radegs_forward")
+    return (rendered, out_color, out_coord, out_mcoord, out_alpha, out_normal, out_depth, out_mdepth, radii, geom.tensor,
+            binning.tensor, img.tensor)
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                                 projmatrix, tan_fovx, tan_fovy, kernel_size, dL_dout_color, dL_dout_coord, dL_dout_mcoord,
+                                 dL_dout_depth, dL_dout_mdepth, dL_dout_alpha, dL_dout_normal, normalmap, sh, degree, campos,
+                                 geomBuffer, R, binningBuffer, imageBuffer, alphas, require_coord, require_depth, debug):
+    _require_gpu(means3D, "means3D")
+    L = library()
+    dev = means3D.device
+    P = int(means3D.size(0))
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
+    fo = dict(dtype=torch.float32, device=dev)
+    mk = torch.empty if P != 0 else torch.zeros
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors = mk((P, 3), **fo), mk((P, 3), **fo), mk((P, 3), **fo)
+    dL_dopacity, dL_dcov3D = mk((P, 1), **fo), mk((P, 6), **fo)
+    dL_dsh = mk((P, M, 3), **fo)
+    dL_dscales, dL_drotations = mk((P, 3), **fo), mk((P, 4), **fo)
+    if P != 0:
+        bg, m3, col = _f32(background, "bg"), _f32(means3D, "means3D"), _f32(colors, "colors_precomp")
+        sc, rot, cov = _f32(scales, "scales"), _f32(rotations, "rotations"), _f32(cov3D_precomp, "cov3D_precomp")
+        vm, pm, cp, shs = _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix"), _f32(campos, "campos"), _f32(sh, "shs")
+        g = [_f32(t, n) for t, n in ((dL_dout_color, "dL_dcolor"), (dL_dout_coord, "dL_dcoord"), (dL_dout_mcoord, "dL_dmcoord"),
+                                     (dL_dout_depth, "dL_ddepth"), (dL_dout_mdepth, "dL_dmdepth"), (dL_dout_alpha, "dL_dalpha"),
+                                     (dL_dout_normal, "dL_dnormal"))]
+        al, nm = _f32(alphas, "alphas"), _f32(normalmap, "normalmap")
+        rad = radii.contiguous()
+        gb, bb, ib = geomBuffer.contiguous(), binningBuffer.contiguous(), imageBuffer.contiguous()
+        if not sc is None and rot is None:
+            raise RuntimeError("scales given without rotations")
+        acc = _Resizable(dev)
+        a = RadegsBwdArgs(P, int(degree), M, int(R), W, H, _ptr(bg), _ptr(m3), _ptr(shs), _ptr(col), _ptr(al), _ptr(sc), _ptr(rot),
+                          _ptr(cov), _ptr(vm), _ptr(pm), _ptr(cp), float(scale_modifier), float(tan_fovx), float(tan_fovy),
+                          float(kernel_size), _ptr(rad), _ptr(nm), _ptr(gb) if gb.numel() else None, _ptr(bb) if bb.numel() else None,
+                          _ptr(ib) if ib.numel() else None, _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(g[4]), _ptr(g[5]),
+                          _ptr(g[6]), _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
+                          _ptr(dL_dsh) if M else None, _ptr(dL_dscales), _ptr(dL_drotations), int(bool(require_coord)),
+                          int(bool(require_depth)), int(bool(debug)))
+        with torch.cuda.device(dev):
+            rc = L.radegs_backward(ctypes.byref(a), acc.cb, None, _stream(dev))
+        if acc.error is not None:
+            raise acc.error
+        _check(rc, "radegs_backward")
+        if sc is None:  # precomputed covariance: scale/rotation grads are identically zero
+            dL_dscales.zero_()
+            dL_drotations.zero_()
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    _require_gpu(means3D, "means3D")
+    L = library()
+    dev = means3D.device
+    P = int(means3D.size(0))
+    present = torch.zeros(P, dtype=torch.bool, device=dev)
+    if P != 0:
+        m3, vm, pm = _f32(means3D, "means3D"), _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix")
+        with torch.cuda.device(dev):
+            rc = L.radegs_mark_visible(P, _ptr(m3), _ptr(vm), _ptr(pm), ctypes.c_void_p(present.data_ptr()), _stream(dev))
+        _check(rc, "radegs_mark_visible")
+    return present
+
+
+def integrate_gaussians_to_points(*_args, **_kwargs):
+    raise NotImplementedError("integrate_gaussians_to_points (GOF point integration for marching tetrahedra, "
+                              "DGR/rasterize_points.cu:269-388) is outside the hot path built so far -- SURVEY.md 8(f) N1")
+
+
+def debug_export(name, dtype, numel, P, R, W, H, require_coord, geomBuffer, binningBuffer, imageBuffer):
+    """Test hook: copy a private state array (see radegs_debug_export in include/radegs.h)."""
+    L = library()
+    dev = geomBuffer.device
+    dst = torch.empty(numel, dtype=dtype, device=dev)
+    with torch.cuda.device(dev):
+        n = L.radegs_debug_export(name.encode(), int(P), int(R), int(W), int(H), int(bool(require_coord)),
+                                  ctypes.c_void_p(geomBuffer.data_ptr()) if geomBuffer.numel() else None,
+                                  ctypes.c_void_p(binningBuffer.data_ptr()) if binningBuffer.numel() else None,
+                                  ctypes.c_void_p(imageBuffer.data_ptr()) if imageBuffer.numel() else None,
+                                  ctypes.c_void_p(dst.data_ptr()), dst.numel() * dst.element_size(), _stream(dev))
+    if n < 0:
+        raise RuntimeError(L.radegs_last_error().decode())
+    return dst

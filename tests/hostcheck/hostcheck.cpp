@@ -1,0 +1,83 @@
+// TEST HARNESS (not product code): runs the product's host+device per-Gaussian math
+// (rade-gs_amd/csrc/rg_*.h) on the CPU so it can be compared bit-for-bit with the oracle in a
+// container that has no GPU.  The product never links this file.
+#include <cstring>
+#include "rg_blend.h"
+#include "rg_preprocess.h"
+#include "rg_preprocess_bwd.h"
+
+using namespace rg;
+
+static Camera make_cam(const float* view, const float* proj, const float* campos, int W, int H, float tanfovx, float tanfovy,
+                       float kernel_size, float scale_modifier) {
+  Camera c;
+  memcpy(c.view, view, 64);
+  memcpy(c.proj, proj, 64);
+  memcpy(c.campos, campos, 12);
+  c.focal_y = H / (2.0f * tanfovy);
+  c.focal_x = W / (2.0f * tanfovx);
+  c.tan_fovx = tanfovx; c.tan_fovy = tanfovy; c.kernel_size = kernel_size; c.scale_modifier = scale_modifier;
+  c.W = W; c.H = H; c.gx = (W + kTile - 1) / kTile; c.gy = (H + kTile - 1) / kTile;
+  return c;
+}
+
+extern "C" {
+
+// out_f: [P][27] = mx,my,cx,cy,cz,op,ts,rgb3,rp2,nrm3,cp6,vp3,depth ; out_i: [P][3] = radius,tiles,clamped
+void hc_preprocess_fwd(int P, int deg, int M, const float* means, const float* scales, const float* rots, const float* cov3D,
+                       const float* opac, const float* shs, const float* colors, const float* view, const float* proj,
+                       const float* campos, int W, int H, float tanfovx, float tanfovy, float kernel_size, float scale_modifier,
+                       float* out_f, int* out_i) {
+  Camera cam = make_cam(view, proj, campos, W, H, tanfovx, tanfovy, kernel_size, scale_modifier);
+  for (int i = 0; i < P; i++) {
+    SplatFwd s;
+    memset(&s, 0, sizeof(s));
+    preprocess_fwd(mk3(means[3 * i], means[3 * i + 1], means[3 * i + 2]), scales ? scales + 3 * i : nullptr, rots ? rots + 4 * i : nullptr,
+                   cov3D ? cov3D + 6 * i : nullptr, opac[i], deg, shs ? shs + (size_t)i * M * 3 : nullptr,
+                   colors ? colors + 3 * i : nullptr, cam, s);
+    float* f = out_f + (size_t)i * 27;
+    f[0] = s.mx; f[1] = s.my; f[2] = s.cx; f[3] = s.cy; f[4] = s.cz; f[5] = s.op; f[6] = s.ts;
+    for (int k = 0; k < 3; k++) f[7 + k] = s.rgb[k];
+    for (int k = 0; k < 2; k++) f[10 + k] = s.rp[k];
+    for (int k = 0; k < 3; k++) f[12 + k] = s.nrm[k];
+    for (int k = 0; k < 6; k++) f[15 + k] = s.cp[k];
+    for (int k = 0; k < 3; k++) f[21 + k] = s.vp[k];
+    f[24] = s.depth; f[25] = 0; f[26] = 0;
+    out_i[3 * i] = s.radius; out_i[3 * i + 1] = s.tiles; out_i[3 * i + 2] = (int)s.clamped;
+  }
+}
+
+// acc: [P][25] in SplatAcc field order (dcolor3,dts,drp2,dnrm3,dmean2D3,dconic3,dop,dvp3,dcp6)
+// out: [P][17] = dmean3D3,dopacity,dcov3D6,dscale3,drot4 ; dsh: [P][M][3]
+void hc_preprocess_bwd(int P, int deg, int M, const float* means, const float* scales, const float* rots, const float* cov3D_pre,
+                       const float* shs, const int* radii, const int* clamped, const float* op_combined, const float* view,
+                       const float* proj, const float* campos, int W, int H, float tanfovx, float tanfovy, float kernel_size,
+                       float scale_modifier, const float* acc, float* out, float* dsh) {
+  Camera cam = make_cam(view, proj, campos, W, H, tanfovx, tanfovy, kernel_size, scale_modifier);
+  for (int i = 0; i < P; i++) {
+    float* o = out + (size_t)i * 17;
+    for (int k = 0; k < 17; k++) o[k] = 0;
+    if (!(radii[i] > 0)) continue;
+    SplatAcc a;
+    memcpy(&a, acc + (size_t)i * 25, sizeof(float) * 25);
+    float cov[6];
+    if (cov3D_pre) memcpy(cov, cov3D_pre + 6 * i, 24);
+    else cov3d_from_scale_rot(scales + 3 * i, scale_modifier, rots + 4 * i, cov);
+    SplatBwd b;
+    memset(&b, 0, sizeof(b));
+    preprocess_bwd(mk3(means[3 * i], means[3 * i + 1], means[3 * i + 2]), scales ? scales + 3 * i : nullptr, rots ? rots + 4 * i : nullptr,
+                   cov, op_combined[i], deg, shs ? shs + (size_t)i * M * 3 : nullptr, (unsigned)clamped[i], cam, a,
+                   dsh ? dsh + (size_t)i * M * 3 : nullptr, b);
+    for (int k = 0; k < 3; k++) o[k] = b.dmean3D[k];
+    o[3] = b.dopacity;
+    for (int k = 0; k < 6; k++) o[4 + k] = b.dcov3D[k];
+    for (int k = 0; k < 3; k++) o[10 + k] = b.dscale[k];
+    for (int k = 0; k < 4; k++) o[13 + k] = b.drot[k];
+  }
+}
+
+float hc_exp_spec(float x) { return exp_spec(x); }
+float hc_splat_power(float cx, float cy, float cz, float dx, float dy) { return splat_power((cx * dx) * dx, cy * dx, cz, dy); }
+float hc_skip_threshold(float op) { return skip_threshold(op); }
+int hc_sizeof_acc() { return (int)sizeof(SplatAcc); }
+}
