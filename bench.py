@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: fwd+bwd Msplats/s of the differentiable splat rasterizer.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one synthetic view: `_C.rasterize_gaussians` followed by
+`_C.rasterize_gaussians_backward` with fixed random cotangents (allocation of outputs/grads included,
+loss arithmetic excluded -- SURVEY.md 8d).  Workload at N=1: BASELINE.json configs[1] ("C2": 1M
+Gaussians, 1920x1080, SH degree 3, RGB + depth + normal).  For N>1 every rank renders its OWN view of
+the replicated Gaussians (weak scaling) and the step ends with one RCCL all-reduce of the 236 B/Gaussian
+parameter gradients.  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel: algorithmic bytes per launch / its average
+                launch duration, measured with HIP events recorded by the library on the launch stream
+                during the timed region
+  cpu_baseline  the CPU oracle (oracle/, a port of the reference algorithm) timed on this box's host
+                cores on the same workload -- a reported baseline, not the target
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "rade-gs_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(P, Pv, R, N, D, c, d):
+    """Per-stage ALGORITHMIC bytes of one view (SURVEY.md 8d split by stage)."""
+    n = 1 if (c or d) else 0
+    K = (D + 1) ** 2
+    G = 36 + 12 * d + 36 * c + 12 * n
+    k = 6  # ceil((32 + tile bits) / 8) for every BASELINE config
+    A = 44 + 36 * c + 12 * d + 12 * n
+    st = {
+        "preprocess_fwd": 52 * P + Pv * (12 * K + 127),
+        "binning": 16 * P + R * (12 + 24 * k + 8),
+        "blend_fwd": R * (4 + G) + N * (24 + 36 * c + 12 * d + 16 * n),
+        "blend_bwd": R * (4 + G) + N * (28 + 36 * c + 12 * d + 28 * n) + Pv * A,
+        "preprocess_bwd": Pv * (12 + 160 + (123 + 12 * K) + (40 + 12 * K)) + 284 * (P - Pv),
+    }
+    st["total"] = sum(st.values())
+    return st
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="C2", help="BASELINE.json config (C1..C5); the headline metric is quoted on C2")
+    ap.add_argument("--points", type=int, default=0, help="override the number of Gaussians (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU path")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import diff_gaussian_rasterization._C as C
+    from synth_scene import CONFIGS, make_config, to_device, upstream_grads
+    from view_parallel import allreduce_gradients
+
+    over = {}
+    if args.points:
+        over["P"] = args.points
+    if world > 1:
+        over["pose"] = "random"  # a different camera per rank ...
+    cfg = dict(CONFIGS[args.config])
+    scene_cpu = make_config(args.config, **over)
+    if world > 1:  # ... over the SAME Gaussians: regenerate rank 0's scene geometry, keep this rank's camera
+        base = make_config(args.config, **{k: v for k, v in over.items() if k != "pose"})
+        cam = make_config(args.config, **dict(over, seed=cfg["seed"] + 1000 + rank, P=8))
+        scene_cpu = base._replace(viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix, campos=cam.campos)
+    s = to_device(scene_cpu, dev)
+    g = {k: v.to(dev) for k, v in upstream_grads(scene_cpu, cfg["seed"]).items()}
+    P, W, H = s.means3D.shape[0], s.W, s.H
+    e = torch.Tensor([])
+
+    def step():
+        fw = C.rasterize_gaussians(s.bg, s.means3D, e, s.opacities, s.scales, s.rotations, 1.0, e, s.viewmatrix, s.projmatrix, s.tanfovx,
+                                   s.tanfovy, s.kernel_size, H, W, s.shs, s.sh_degree, s.campos, False, s.require_coord,
+                                   s.require_depth, False)
+        R, color, coord, mcoord, alpha, normal, depth, mdepth, radii, geom, binning, img = fw
+        bw = C.rasterize_gaussians_backward(s.bg, s.means3D, radii, e, s.scales, s.rotations, 1.0, e, s.viewmatrix, s.projmatrix,
+                                            s.tanfovx, s.tanfovy, s.kernel_size, g["color"], g["coord"], g["mcoord"], g["depth"],
+                                            g["mdepth"], g["alpha"], g["normal"], normal, s.shs, s.sh_degree, s.campos, geom, R,
+                                            binning, img, alpha, s.require_coord, s.require_depth, False)
+        grads = dict(dL_dmeans3D=bw[3], dL_dsh=bw[5], dL_dopacity=bw[2], dL_dscales=bw[6], dL_drotations=bw[7])
+        if world > 1:
+            grads = allreduce_gradients(grads, average=True)
+        return R, radii, grads
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        R, radii, _ = step()
+    fence()
+    C.profile_collect()
+    C.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        R, radii, _ = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    C.profile_enable(False)
+    stages = C.profile_collect()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * P / 1e6 / (elapsed / args.steps)
+
+    if rank == 0:
+        Pv = int((radii > 0).sum().item())
+        c, d = int(s.require_coord), int(s.require_depth)
+        ab = algorithmic_bytes(P, Pv, R, W * H, s.sh_degree, c, d)
+        ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in stages.items()}
+        grouped = {"preprocess_fwd": ms["preprocess_fwd"],
+                   "binning": ms["sort_depth"] + ms["scan"] + ms["emit_instances"] + ms["sort_tile"] + ms["tile_ranges"],
+                   "blend_fwd": ms["blend_fwd"], "blend_bwd": ms["blend_bwd"] + ms["acc_zero"], "preprocess_bwd": ms["preprocess_bwd"]}
+        dom = max(("preprocess_fwd", "blend_fwd", "blend_bwd", "preprocess_bwd"), key=lambda k: ms[k] if k != "blend_bwd" else ms["blend_bwd"])
+        dom_ms = ms[dom]
+        achieved = ab[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        gpu_ms = sum(grouped.values())
+        out = {
+            "metric": "fwd+bwd Msplats/s @1080p, 1M Gaussians; depth L1 vs ref", "value": round(value, 2), "unit": "Msplats/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH degree {s.sh_degree}, fwd+bwd single view per GPU, "
+                                   f"RGB{'+coord' if c else ''}{'+depth' if d else ''}{'+normal' if (c or d) else ''}",
+                       "parallelism": f"view-parallel x{world}" + (", RCCL all-reduce of 236 B/Gaussian grads" if world > 1 else ""),
+                       "num_rendered": int(R), "visible": Pv},
+            "roofline": {"bound": "hbm", "kernel": dom + "_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(ab[dom]), "avg_launch_ms": round(dom_ms, 4)},
+            "path_roofline": {"algorithmic_bytes_per_view": int(ab["total"]), "gpu_ms_per_view": round(gpu_ms, 4),
+                              "achieved_GBs_gpu_time": round(ab["total"] / (gpu_ms * 1e-3) / 1e9, 1) if gpu_ms > 0 else 0.0,
+                              "achieved_GBs_wall": round(ab["total"] / (ms_per_step * 1e-3) / 1e9, 1),
+                              "frac_wall": round(ab["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "stages_ms": {k: round(v, 4) for k, v in ms.items()},
+            "stage_GBs": {k: round(ab[k] / (grouped[k] * 1e-3) / 1e9, 1) if grouped[k] > 0 else 0.0 for k in grouped},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene_cpu, cfg["seed"])
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(scene_cpu, seed):
+    """The oracle (a CPU port of the reference algorithm; the reference itself is CUDA-only and cannot
+    run here) timed on this box's host cores: one fwd+bwd pass over the SAME view."""
+    from oracle.oracle import Oracle
+    from synth_scene import upstream_grads
+    s = scene_cpu
+    cores = os.cpu_count() or 1
+    o = Oracle(bg=s.bg, means3D=s.means3D, opacities=s.opacities, viewmatrix=s.viewmatrix, projmatrix=s.projmatrix, campos=s.campos,
+               tanfovx=s.tanfovx, tanfovy=s.tanfovy, image_height=s.H, image_width=s.W, shs=s.shs, scales=s.scales,
+               rotations=s.rotations, sh_degree=s.sh_degree, kernel_size=s.kernel_size, require_coord=s.require_coord,
+               require_depth=s.require_depth, nthreads=cores)
+    g = upstream_grads(s, seed)
+    t0 = time.perf_counter()
+    o.forward()
+    t1 = time.perf_counter()
+    o.backward(g["color"], g["coord"], g["mcoord"], g["depth"], g["mdepth"], g["alpha"], g["normal"])
+    t2 = time.perf_counter()
+    P = s.means3D.shape[0]
+    return {"value": round(P / 1e6 / (t2 - t0), 4), "unit": "Msplats/s", "cores": cores, "kind": "port",
+            "sample": f"1 fwd+bwd pass over the full workload view ({P} Gaussians, {s.W}x{s.H}); fwd {t1 - t0:.2f} s, bwd {t2 - t1:.2f} s, "
+                      f"OpenMP over Gaussians/tiles"}
+
+
+if __name__ == "__main__":
+    main()

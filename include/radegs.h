@@ -141,6 +141,15 @@ size_t radegs_binning_bytes(int R);
 long long radegs_debug_export(const char* name, int P, int R, int width, int height, int require_coord, const void* geom_buffer,
                               const void* binning_buffer, const void* image_buffer, void* dst, size_t dst_bytes, void* stream);
 
+/* Per-stage timing with HIP events recorded on the launch stream (used by bench.py for the live
+ * roofline measurement).  enable(1) -> every subsequent forward/backward records an event pair per
+ * stage; collect() waits for them, adds each stage's elapsed ms / launch count into the arrays
+ * (n >= radegs_profile_num_stages()) and clears the log. */
+void radegs_profile_enable(int on);
+int radegs_profile_num_stages(void);
+const char* radegs_profile_stage_name(int i);
+int radegs_profile_collect(float* ms_total, int* count, int n);
+
 const char* radegs_last_error(void);
 const char* radegs_version(void);
 

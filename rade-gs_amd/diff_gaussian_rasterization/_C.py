@@ -61,7 +61,8 @@ class RadegsBwdArgs(ctypes.Structure):
 
 # every symbol include/radegs.h declares
 EXPORTED_SYMBOLS = ("radegs_forward", "radegs_backward", "radegs_mark_visible", "radegs_geometry_bytes", "radegs_image_bytes",
-                    "radegs_binning_bytes", "radegs_debug_export", "radegs_last_error", "radegs_version")
+                    "radegs_binning_bytes", "radegs_debug_export", "radegs_last_error", "radegs_version", "radegs_profile_enable",
+                    "radegs_profile_num_stages", "radegs_profile_stage_name", "radegs_profile_collect")
 
 _lib = None
 
@@ -92,6 +93,13 @@ def library():
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.radegs_last_error.restype = ctypes.c_char_p
         L.radegs_version.restype = ctypes.c_char_p
+        L.radegs_profile_enable.restype = None
+        L.radegs_profile_enable.argtypes = [ctypes.c_int]
+        L.radegs_profile_num_stages.restype = ctypes.c_int
+        L.radegs_profile_stage_name.restype = ctypes.c_char_p
+        L.radegs_profile_stage_name.argtypes = [ctypes.c_int]
+        L.radegs_profile_collect.restype = ctypes.c_int
+        L.radegs_profile_collect.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int), ctypes.c_int]
         _lib = L
     return _lib
 
@@ -271,3 +279,17 @@ def debug_export(name, dtype, numel, P, R, W, H, require_coord, geomBuffer, binn
     if n < 0:
         raise RuntimeError(L.radegs_last_error().decode())
     return dst
+
+
+def profile_enable(on=True):
+    library().radegs_profile_enable(int(bool(on)))
+
+
+def profile_collect():
+    """{stage name: (total ms, launches)} since the last collect (HIP events on the launch stream)."""
+    L = library()
+    n = L.radegs_profile_num_stages()
+    ms = (ctypes.c_float * n)()
+    cnt = (ctypes.c_int * n)()
+    L.radegs_profile_collect(ms, cnt, n)
+    return {L.radegs_profile_stage_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}

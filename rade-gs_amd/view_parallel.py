@@ -1,0 +1,57 @@
+"""View-level data parallelism for the rasterizer: one process per GPU, replicated Gaussians, each rank
+renders its own view; the only exchange step is the sum of the parameter gradients.
+
+The reference has no distributed code at all (single process, `cuda:0`); this is the extension
+BASELINE.json's north_star asks for.  The six gradient tensors (xyz, SH, opacity, scaling, rotation
+= 59 floats = 236 B per Gaussian) are packed into ONE flat bucket so a single RCCL all-reduce moves
+them over xGMI; with `backend="gloo"` the same code runs on CPU tensors (tests/test_dist_gloo.py).
+"""
+from typing import Dict, Iterable, List
+
+import torch
+import torch.distributed as dist
+
+GRAD_KEYS = ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations")
+
+
+def pack(tensors: Iterable[torch.Tensor]) -> torch.Tensor:
+    return torch.cat([t.reshape(-1) for t in tensors])
+
+
+def unpack(flat: torch.Tensor, like: List[torch.Tensor]) -> List[torch.Tensor]:
+    out, off = [], 0
+    for t in like:
+        n = t.numel()
+        out.append(flat[off:off + n].view_as(t))
+        off += n
+    return out
+
+
+def allreduce_gradients(grads: Dict[str, torch.Tensor], average: bool = True, group=None) -> Dict[str, torch.Tensor]:
+    """Sum (or mean) of the per-view gradients over all ranks, one collective for the whole bucket.
+    Mean keeps the single-view learning-rate scale of the reference's batch-1 training loop."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return grads
+    keys = [k for k in GRAD_KEYS if grads.get(k) is not None]
+    flat = pack(grads[k] for k in keys)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat /= dist.get_world_size(group)
+    out = dict(grads)
+    for k, t in zip(keys, unpack(flat, [grads[k] for k in keys])):
+        out[k] = t
+    return out
+
+
+def allreduce_densification_stats(grad_norm_xy: torch.Tensor, grad_norm_abs: torch.Tensor, visible: torch.Tensor,
+                                  radii: torch.Tensor, group=None):
+    """Keeps densification consistent across ranks (scene/gaussian_model.py:743-747, train.py:187):
+    gradient-norm accumulators and visibility counts add up, radii take the max."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return grad_norm_xy, grad_norm_abs, visible, radii
+    flat = pack([grad_norm_xy.float(), grad_norm_abs.float(), visible.float()])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    a, b, c = unpack(flat, [grad_norm_xy, grad_norm_abs, visible])
+    r = radii.clone()
+    dist.all_reduce(r, op=dist.ReduceOp.MAX, group=group)
+    return a.to(grad_norm_xy.dtype), b.to(grad_norm_abs.dtype), c.to(visible.dtype), r

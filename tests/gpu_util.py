@@ -1,0 +1,80 @@
+"""Runs the HIP operator on a synthetic Scene through the public drop-in API (test infrastructure)."""
+import numpy as np
+import torch
+
+from synth_scene import Scene, to_device
+
+
+def settings_for(s: Scene, device, debug=False):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(
+        image_height=s.H, image_width=s.W, tanfovx=s.tanfovx, tanfovy=s.tanfovy, kernel_size=s.kernel_size, bg=s.bg.to(device),
+        scale_modifier=1.0, viewmatrix=s.viewmatrix.to(device), projmatrix=s.projmatrix.to(device), sh_degree=s.sh_degree,
+        campos=s.campos.to(device), prefiltered=False, require_depth=s.require_depth, require_coord=s.require_coord, debug=debug)
+
+
+class HipRun:
+    """forward (+ optional backward) of one view; keeps the private state for index checks."""
+
+    def __init__(self, s: Scene, device="cuda:0", colors=None, cov3D=None, debug=False):
+        import diff_gaussian_rasterization._C as C
+        self.C = C
+        self.s = s
+        self.dev = torch.device(device)
+        d = to_device(s, self.dev)
+        self.P = s.means3D.shape[0]
+        self.means3D = d.means3D.clone().requires_grad_(True)
+        self.means2D = torch.zeros_like(d.means3D, requires_grad=True)
+        self.opacities = d.opacities.clone().requires_grad_(True)
+        self.shs = None if colors is not None else d.shs.clone().requires_grad_(True)
+        self.colors = None if colors is None else colors.to(self.dev).clone().requires_grad_(True)
+        self.scales = None if cov3D is not None else d.scales.clone().requires_grad_(True)
+        self.rotations = None if cov3D is not None else d.rotations.clone().requires_grad_(True)
+        self.cov3D = None if cov3D is None else cov3D.to(self.dev).clone().requires_grad_(True)
+        self.rs = settings_for(s, self.dev, debug)
+        self.state = None
+
+    def forward(self):
+        """through the autograd operator; also captures the state buffers via a direct `_C` call"""
+        from diff_gaussian_rasterization import GaussianRasterizer
+        r = GaussianRasterizer(self.rs)
+        self.out = r(self.means3D, self.means2D, self.opacities, shs=self.shs, colors_precomp=self.colors, scales=self.scales,
+                     rotations=self.rotations, cov3D_precomp=self.cov3D)
+        return self.out
+
+    def forward_native(self):
+        e = torch.Tensor([])
+        rs = self.rs
+        res = self.C.rasterize_gaussians(rs.bg, self.means3D.detach(), e if self.colors is None else self.colors.detach(),
+                                         self.opacities.detach(), e if self.scales is None else self.scales.detach(),
+                                         e if self.rotations is None else self.rotations.detach(), rs.scale_modifier,
+                                         e if self.cov3D is None else self.cov3D.detach(), rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+                                         rs.tanfovy, rs.kernel_size, rs.image_height, rs.image_width,
+                                         e if self.shs is None else self.shs.detach(), rs.sh_degree, rs.campos, False,
+                                         rs.require_coord, rs.require_depth, rs.debug)
+        self.state = res
+        return res
+
+    def export(self, name, dtype, numel):
+        R, geom, binning, img = self.state[0], self.state[9], self.state[10], self.state[11]
+        return self.C.debug_export(name, dtype, numel, self.P, R, self.s.W, self.s.H, self.s.require_coord, geom, binning, img).cpu().numpy()
+
+    def backward(self, g):
+        color, radii, coord, mcoord, depth, mdepth, alpha, normal = self.out
+        dev = self.dev
+        loss = (color * g["color"].to(dev)).sum() + (alpha * g["alpha"].to(dev)).sum()
+        loss = loss + (coord * g["coord"].to(dev)).sum() + (mcoord * g["mcoord"].to(dev)).sum()
+        loss = loss + (depth * g["depth"].to(dev)).sum() + (mdepth * g["mdepth"].to(dev)).sum()
+        loss = loss + (normal * g["normal"].to(dev)).sum()
+        loss.backward()
+        torch.cuda.synchronize(dev)
+
+        def n(t):
+            return None if t is None or t.grad is None else t.grad.detach().cpu().numpy()
+
+        return dict(dL_dmeans2D=n(self.means2D), dL_dcolors=n(self.colors), dL_dopacity=n(self.opacities), dL_dmeans3D=n(self.means3D),
+                    dL_dcov3D=n(self.cov3D), dL_dsh=n(self.shs), dL_dscales=n(self.scales), dL_drotations=n(self.rotations))
+
+
+def outputs_numpy(out):
+    return [o.detach().cpu().numpy() for o in out]
