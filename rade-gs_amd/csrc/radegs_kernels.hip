@@ -174,18 +174,19 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
   const uint2 range = a.ranges[tile];
   const int n = (int)(range.y - range.x);
 
-  float pixfy[PPL], T[PPL], Cr[PPL], Cg[PPL], Cb[PPL], weight[PPL];
+  // Tw is the working transmittance: it equals T until the pixel terminates, then it is forced to
+  // 0 -- any later candidate then fails `T*(1-alpha) >= 1e-4` by itself, which is exactly "done".
+  float pixfy[PPL], T[PPL], Tw[PPL], Cr[PPL], Cg[PPL], Cb[PPL], weight[PPL];
   float Dep[PPL], mDep[PPL], Nx[PPL], Ny[PPL], Nz[PPL];
   float Co[COORD ? PPL : 1][3], mCo[COORD ? PPL : 1][3];
   uint32_t last_c[PPL], max_c[PPL];
-  bool done[PPL], inside[PPL];
+  bool inside[PPL];
 #pragma unroll
   for (int s = 0; s < PPL; s++) {
     const int py = py0 + 4 * s;
     pixfy[s] = (float)py;
     inside[s] = px < W && py < H;
-    done[s] = !inside[s];
-    T[s] = 1.0f; Cr[s] = Cg[s] = Cb[s] = 0.f; weight[s] = 0.f;
+    T[s] = 1.0f; Tw[s] = inside[s] ? 1.0f : 0.0f; Cr[s] = Cg[s] = Cb[s] = 0.f; weight[s] = 0.f;
     Dep[s] = mDep[s] = 0.f; Nx[s] = Ny[s] = Nz[s] = 0.f;
     last_c[s] = 0; max_c[s] = 0xFFFFFFFFu;
     if constexpr (COORD) {
@@ -197,7 +198,7 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
   {
     bool d = true;
 #pragma unroll
-    for (int s = 0; s < PPL; s++) d = d && done[s];
+    for (int s = 0; s < PPL; s++) d = d && (Tw[s] == 0.0f);
     all_done = __all(d);
   }
 
@@ -231,7 +232,7 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
       for (int s = 0; s < PPL; s++) {
         const float dy = A.y - pixfy[s];
         power[s] = splat_power(a_x, b_xy, B.x, dy);
-        cand[s] = !done[s] && !(power[s] > 0.0f) && !(power[s] < B.z);
+        cand[s] = !(power[s] > 0.0f) && !(power[s] < B.z);
         anyc = anyc || cand[s];
       }
       if (!__any(anyc)) continue;
@@ -246,10 +247,10 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
           const float G = exp_spec(power[s]);
           const float alpha = fminf(0.99f, B.y * G);
           if (!(alpha < 1.0f / 255.0f)) {
-            const float test_T = T[s] * (1 - alpha);
+            const float test_T = Tw[s] * (1 - alpha);
             if (test_T < 0.0001f) {
-              done[s] = true;
-              newly_done = true;
+              newly_done = newly_done || (Tw[s] != 0.0f);
+              Tw[s] = 0.0f;
             } else {
               const float aT = alpha * T[s];
               const float dy = A.y - pixfy[s];
@@ -273,6 +274,7 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
               }
               weight[s] += aT;
               T[s] = test_T;
+              Tw[s] = test_T;
               last_c[s] = contributor;
             }
           }
@@ -281,7 +283,7 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
       if (__any(newly_done)) {
         bool d = true;
 #pragma unroll
-        for (int s = 0; s < PPL; s++) d = d && done[s];
+        for (int s = 0; s < PPL; s++) d = d && (Tw[s] == 0.0f);
         all_done = __all(d);
         if (all_done) break;
       }
@@ -345,32 +347,58 @@ struct BlendBwdArgs {
 };
 
 // In: v[i] = this lane's partial sum of component i.  Out (return value): the wave-wide total of
-// component (lane & (N-1)).  log2(N) butterfly stages halve the live components while doubling
-// the lanes summed; the remaining lane bits are folded with plain xor exchanges.
-template <int N>
+// component (lane & (N-1)).  Each butterfly stage halves the live components while doubling the
+// lanes summed: lanes whose stage bit is set keep the upper half of the components, the others the
+// lower half, and every lane hands the half it drops to a partner of the opposite class.  The four
+// in-row stages use DPP (no LDS crossbar): row_ror:8 (= xor 8), row_half_mirror (bit 2 flips,
+// bit 3 kept), quad_perm xor 2, quad_perm xor 1 -- together they span all 16 lanes of a row.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+template <int HALF, int BIT, int CTRL>
+__device__ __forceinline__ void bfly_stage_dpp(float* v, int lane) {
+  const bool up = (lane >> BIT) & 1;
+#pragma unroll
+  for (int i = 0; i < HALF; i++) {
+    const float send = up ? v[i] : v[i + HALF];
+    const float keep = up ? v[i + HALF] : v[i];
+    v[i] = keep + dpp_mov<CTRL>(send);
+  }
+}
+template <int HALF, int BIT>
+__device__ __forceinline__ void bfly_stage_xor(float* v, int lane) {
+  const bool up = (lane >> BIT) & 1;
+#pragma unroll
+  for (int i = 0; i < HALF; i++) {
+    const float send = up ? v[i] : v[i + HALF];
+    const float keep = up ? v[i + HALF] : v[i];
+    v[i] = keep + __shfl_xor(send, 1 << BIT);
+  }
+}
+template <int N, bool DPP>
 __device__ __forceinline__ float wave_reduce_scatter(float (&v)[N], int lane) {
-  int half = N / 2;
-#pragma unroll
-  for (int bit = (N == 32 ? 4 : 3); bit >= 0; --bit) {
-    const bool up = (lane >> bit) & 1;
-#pragma unroll
-    for (int i = 0; i < N / 2; i++) {
-      if (i < half) {
-        const float send = up ? v[i] : v[i + half];
-        const float keep = up ? v[i + half] : v[i];
-        v[i] = keep + __shfl_xor(send, 1 << bit);
-      }
-    }
-    half >>= 1;
+  if constexpr (N == 32) bfly_stage_xor<16, 4>(v, lane);
+  if constexpr (DPP) {
+    bfly_stage_dpp<8, 3, 0x128>(v, lane);  // row_ror:8
+    bfly_stage_dpp<4, 2, 0x141>(v, lane);  // row_half_mirror
+    bfly_stage_dpp<2, 1, 0x4E>(v, lane);   // quad_perm [2,3,0,1]
+    bfly_stage_dpp<1, 0, 0xB1>(v, lane);   // quad_perm [1,0,3,2]
+  } else {
+    bfly_stage_xor<8, 3>(v, lane);
+    bfly_stage_xor<4, 2>(v, lane);
+    bfly_stage_xor<2, 1>(v, lane);
+    bfly_stage_xor<1, 0>(v, lane);
   }
   float r = v[0];
-  if (N == 16) r += __shfl_xor(r, 16);
+  if constexpr (N == 16) r += __shfl_xor(r, 16);
   r += __shfl_xor(r, 32);
   return r;
 }
 
-template <bool COORD, bool DEPTH, int PPL>
-__global__ void __launch_bounds__(64) blend_bwd_kernel(const BlendBwdArgs a) {
+// second launch-bound = waves per SIMD the register allocator must leave room for
+template <bool COORD, bool DEPTH, int PPL, bool DPP>
+__global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 2 : (PPL == 2 ? 3 : 5)) : (PPL == 4 ? 3 : (PPL == 2 ? 4 : 6)))) blend_bwd_kernel(const BlendBwdArgs a) {
   constexpr bool NORMAL = COORD || DEPTH;
   constexpr int WPT = 4 / PPL;
   constexpr int REC = COORD ? 32 : 16;
@@ -390,11 +418,15 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(const BlendBwdArgs a) {
   const uint2 range = a.ranges[tile];
 
   // ---- per-pixel prologue (backward.cu:706-781) ----
-  float pixfy[PPL], T[PPL], T_final[PPL], last_alpha[PPL], acc_a[PPL], dLa[PPL], bgdot[PPL];
-  float dLc[PPL][3], accC[PPL][3], lastC[PPL][3];
-  float dLt[PPL], dLmt[PPL], accT[PPL], lastT[PPL];
-  float dLn[PPL][3], accN[PPL][3], lastN[PPL][3];
-  float dLco[COORD ? PPL : 1][3], dLmco[COORD ? PPL : 1][3], accCo[COORD ? PPL : 1][3], lastCo[COORD ? PPL : 1][3];
+  // The reference keeps last_alpha/last_color/... and folds the PREVIOUS contributor into the
+  // "behind" accumulators at the start of the next one (backward.cu:870,900,930,949,962).  Folding
+  // the CURRENT contributor in at the end of its own iteration is the same arithmetic on the same
+  // operands (bit-identical values), and needs no last_* registers or copies.
+  float pixfy[PPL], T[PPL], acc_a[PPL], dLa[PPL], tb[PPL];
+  float dLc[PPL][3], accC[PPL][3];
+  float dLt[PPL], dLmt[PPL], accT[PPL];
+  float dLn[PPL][3], accN[PPL][3];
+  float dLco[COORD ? PPL : 1][3], dLmco[COORD ? PPL : 1][3], accCo[COORD ? PPL : 1][3];
   uint32_t last_c[PPL], max_cm1[PPL];
   uint32_t wave_last = 0;
   const float pnx = (pixfx - W / 2.f) / a.focal_x;
@@ -405,23 +437,24 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(const BlendBwdArgs a) {
     const bool inside = px < W && py < H;
     const size_t pix = inside ? (size_t)W * py + px : 0;
     const float alpha_px = inside ? a.alphas[pix] : 0.f;
-    T_final[s] = inside ? (1 - alpha_px) : 0.f;
+    const float T_final = inside ? (1 - alpha_px) : 0.f;
     const float w_final = alpha_px;
-    T[s] = T_final[s];
+    T[s] = T_final;
     last_c[s] = inside ? a.n_contrib[pix] : 0u;
     max_cm1[s] = (inside ? a.n_contrib[pix + HW] : 0u) - 1u;  // compared against the 0-based position
     wave_last = max(wave_last, last_c[s]);
-    last_alpha[s] = 0.f; acc_a[s] = 0.f;
-    dLt[s] = dLmt[s] = 0.f; accT[s] = lastT[s] = 0.f;
+    acc_a[s] = 0.f;
+    dLt[s] = dLmt[s] = 0.f; accT[s] = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       dLc[s][c] = inside ? a.dL_dpix[c * HW + pix] : 0.f;
-      accC[s][c] = lastC[s][c] = 0.f;
-      dLn[s][c] = 0.f; accN[s][c] = lastN[s][c] = 0.f;
-      if constexpr (COORD) { dLco[s][c] = dLmco[s][c] = 0.f; accCo[s][c] = lastCo[s][c] = 0.f; }
+      accC[s][c] = 0.f;
+      dLn[s][c] = 0.f; accN[s][c] = 0.f;
+      if constexpr (COORD) { dLco[s][c] = dLmco[s][c] = 0.f; accCo[s][c] = 0.f; }
     }
     dLa[s] = inside ? a.dL_dalpha[pix] : 0.f;
-    bgdot[s] = a.bg[0] * dLc[s][0] + a.bg[1] * dLc[s][1] + a.bg[2] * dLc[s][2];
+    // background term of dL/dalpha: (-T_final/(1-alpha)) * <bg, dL_dpixel>  (backward.cu:972-975)
+    tb[s] = -T_final * (a.bg[0] * dLc[s][0] + a.bg[1] * dLc[s][1] + a.bg[2] * dLc[s][2]);
     if (NORMAL && inside) {
       const float ww = w_final * w_final;
       const float pny = (pixfy[s] - H / 2.f) / a.focal_y;
@@ -511,19 +544,17 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(const BlendBwdArgs a) {
             contributed = true;
             const float dy = A.y - pixfy[s];
             const float one_m_a = 1.f - alpha;
-            const float inv1ma = 1.0f / one_m_a;
+            const float inv1ma = __builtin_amdgcn_rcpf(one_m_a);  // 1 ulp; no decision depends on T here
             T[s] = T[s] * inv1ma;
             const float dch = alpha * T[s];
-            const float la = last_alpha[s], one_m_la = 1.f - la;
             float dL_dopa = 0.f;
             {
               const float col[3] = {C.x, C.y, C.z};
 #pragma unroll
               for (int c = 0; c < 3; c++) {
-                accC[s][c] = fmaf(la, lastC[s][c], one_m_la * accC[s][c]);
-                lastC[s][c] = col[c];
                 dL_dopa = fmaf(col[c] - accC[s][c], dLc[s][c], dL_dopa);
                 gv[c] = fmaf(dch, dLc[s][c], gv[c]);
+                accC[s][c] = fmaf(alpha, col[c], one_m_a * accC[s][c]);
               }
             }
             float dco[3] = {0.f, 0.f, 0.f}, dt_ = 0.f;
@@ -533,9 +564,8 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(const BlendBwdArgs a) {
 #pragma unroll
               for (int c = 0; c < 3; c++) {
                 const float cc = fmaf(cpy[c], dy, fmaf(cpx[c], dx, vp[c]));
-                accCo[s][c] = fmaf(la, lastCo[s][c], one_m_la * accCo[s][c]);
-                lastCo[s][c] = cc;
                 dL_dopa = fmaf(cc - accCo[s][c], dLco[s][c], dL_dopa);
+                accCo[s][c] = fmaf(alpha, cc, one_m_a * accCo[s][c]);
                 dco[c] = dch * dLco[s][c];
                 if (is_median) dco[c] += dLmco[s][c];
                 gv[16 + c] += dco[c];
@@ -545,9 +575,8 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(const BlendBwdArgs a) {
             }
             if constexpr (DEPTH) {
               const float t = B.w + fmaf(C.w, dx, Dq.x * dy);
-              accT[s] = fmaf(la, lastT[s], one_m_la * accT[s]);
-              lastT[s] = t;
               dL_dopa = fmaf(t - accT[s], dLt[s], dL_dopa);
+              accT[s] = fmaf(alpha, t, one_m_a * accT[s]);
               dt_ = dch * dLt[s];
               if (is_median) dt_ += dLmt[s];
               gv[3] += dt_;
@@ -558,17 +587,15 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(const BlendBwdArgs a) {
               const float nn[3] = {Dq.y, Dq.z, Dq.w};
 #pragma unroll
               for (int c = 0; c < 3; c++) {
-                accN[s][c] = fmaf(la, lastN[s][c], one_m_la * accN[s][c]);
-                lastN[s][c] = nn[c];
                 dL_dopa = fmaf(nn[c] - accN[s][c], dLn[s][c], dL_dopa);
                 gv[6 + c] = fmaf(dch, dLn[s][c], gv[6 + c]);
+                accN[s][c] = fmaf(alpha, nn[c], one_m_a * accN[s][c]);
               }
             }
-            acc_a[s] = fmaf(one_m_la, acc_a[s], la);
             dL_dopa = fmaf(1 - acc_a[s], dLa[s], dL_dopa);
+            acc_a[s] = fmaf(one_m_a, acc_a[s], alpha);
             dL_dopa *= T[s];
-            last_alpha[s] = alpha;
-            dL_dopa = fmaf(-T_final[s] * inv1ma, bgdot[s], dL_dopa);
+            dL_dopa = fmaf(inv1ma, tb[s], dL_dopa);
 
             const float dL_dG = B.y * dL_dopa;
             const float gdx = G * dx, gdy = G * dy;
@@ -595,7 +622,7 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(const BlendBwdArgs a) {
         }
       }
       if (!__any(contributed)) continue;
-      const float tot = wave_reduce_scatter<REC>(gv, lane);
+      const float tot = wave_reduce_scatter<REC, DPP>(gv, lane);
       if (lane < (COORD ? 25 : 16)) unsafeAtomicAdd(a.acc + (size_t)lds_id[j] * REC + lane, tot);
     }
   }

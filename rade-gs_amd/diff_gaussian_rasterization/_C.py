@@ -65,6 +65,9 @@ EXPORTED_SYMBOLS = ("radegs_forward", "radegs_backward", "radegs_mark_visible", 
                     "radegs_profile_num_stages", "radegs_profile_stage_name", "radegs_profile_collect")
 
 _lib = None
+# test hook: when True, the per-Gaussian accumulation scratch of the last backward is kept in LAST_ACC
+KEEP_ACC = False
+LAST_ACC = None
 
 
 def library():
@@ -240,6 +243,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         if acc.error is not None:
             raise acc.error
         _check(rc, "radegs_backward")
+        if KEEP_ACC:
+            global LAST_ACC
+            LAST_ACC = acc.tensor.view(torch.float32)
         if sc is None:  # precomputed covariance: scale/rotation grads are identically zero
             dL_dscales.zero_()
             dL_drotations.zero_()

@@ -56,20 +56,48 @@ def check_forward(s, colors=None, cov3D=None):
     return o, h
 
 
-def check_backward(s, o, colors=None, cov3D=None, seed=0):
+def check_backward(s, o, colors=None, cov3D=None, seed=0, ill_mask=None):
+    """ill_mask: rows (Gaussians) whose covariance is (nearly) singular.  Their per-Gaussian chain rule
+    multiplies the accumulated sums by ~1/lambda_min (backward.cu:333-350), so the 1e-7 relative fp32
+    reordering noise of the sums is amplified without bound; for those rows the check moves to where the
+    noise enters -- the blend backward's per-Gaussian sums -- and only requires finite outputs after the
+    chain rule (which is bit-exact given identical sums: tests/test_hostcheck.py)."""
+    import diff_gaussian_rasterization._C as C
     from gpu_util import HipRun
     g = upstream_grads(s, seed)
     ref = oracle_backward(o, g)
     h = HipRun(s, _dev(), colors=colors, cov3D=cov3D)
     h.forward()
-    got = h.backward(g)
+    C.KEEP_ACC = True
+    try:
+        got = h.backward(g)
+        acc = C.LAST_ACC.cpu().numpy()
+    finally:
+        C.KEEP_ACC = False
+    P = s.means3D.shape[0]
+    # ---- the blend backward's sums (SplatAcc order), all rows ----
+    rec = 32 if s.require_coord else 16
+    acc = acc[: P * rec].reshape(P, rec)
+    dc = o.get("acc_dconic", (P, 4))
+    ref_acc = np.concatenate([o.get("acc_dcolors", (P, 3)), o.get("dL_dts", (P, 1)), o.get("dL_dray_planes", (P, 2)),
+                              o.get("dL_dnormals", (P, 3)), o.get("acc_dmeans2D", (P, 3)), dc[:, [0, 1, 3]],
+                              o.get("acc_dopacity", (P, 1)), o.get("dL_dview_points", (P, 3)), o.get("dL_dcamera_planes", (P, 6))], 1)
+    vis = o.get("radii") > 0
+    for c in range(rec if rec == 16 else 25):
+        a, b = acc[vis, c], ref_acc[vis, c]
+        scale = float(np.abs(b).max()) + 1e-30
+        assert close(a, b, atol=ATOL + 2e-6 * scale, rtol=1e-3).all(), f"acc[{c}] max abs diff {np.abs(a - b).max():.3e} (scale {scale:.3e})"
+        assert frac_close(a, b) > 0.995, f"acc[{c}]"
+    # ---- returned gradients ----
     report = {}
+    rows = np.ones(P, bool) if ill_mask is None else ~ill_mask
     for k, b in ref.items():
         a = got[k]
         if a is None:
             continue
         b = b.reshape(a.shape)
         assert not np.isnan(a).any(), k
+        a, b = a[rows], b[rows]
         # strict bound on (nearly) everything; the remainder must sit inside the fp32 summation-order
         # band of this tensor (scale = its own magnitude)
         strict = frac_close(a, b)
@@ -121,7 +149,8 @@ def test_flat_gaussians_ill_conditioned_branch():
     s = _flat_scene(make_scene(2500, 160, 120, sh_degree=1, mu_px=3.0, seed=12, kernel_size=0.0, pose="random", require_coord=True,
                                require_depth=True))
     o, _ = check_forward(s)
-    check_backward(s, o, seed=12)
+    sc = s.scales.numpy()
+    check_backward(s, o, seed=12, ill_mask=(sc.min(1) / sc.max(1)) < 1e-2)
 
 
 def test_empty_culled_and_single():
