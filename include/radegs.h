@@ -5,11 +5,11 @@
  * point replaces one static method of the reference's native interface
  * (DGR = /root/reference/submodules/diff-gaussian-rasterization):
  *
- *   radegs_forward       <-  CudaRasterizer::Rasterizer::forward    DGR/cuda_rasterizer/rasterizer.h:33-68
+ *   radegs_forward       <-  CudaRasterizer::Rasterizer::forward    DGR/cuda_rasterizer/rasterizer.h:31-63
  *                            (called from RasterizeGaussiansCUDA,    DGR/rasterize_points.cu:36-133)
- *   radegs_backward      <-  CudaRasterizer::Rasterizer::backward   DGR/cuda_rasterizer/rasterizer.h:99-146
+ *   radegs_backward      <-  CudaRasterizer::Rasterizer::backward   DGR/cuda_rasterizer/rasterizer.h:65-110
  *                            (called from RasterizeGaussiansBackwardCUDA, DGR/rasterize_points.cu:136-246)
- *   radegs_mark_visible  <-  CudaRasterizer::Rasterizer::markVisible DGR/cuda_rasterizer/rasterizer.h:26-31
+ *   radegs_mark_visible  <-  CudaRasterizer::Rasterizer::markVisible DGR/cuda_rasterizer/rasterizer.h:24-29
  *                            (called from markVisible,               DGR/rasterize_points.cu:248-267)
  *
  * Conventions kept from the reference:

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""gpurun_out/profiles_<tag>/ (scratch, written on the GPU box by scripts/gpu_profile.sh) ->
+profiles/<tag>_* (tracked): bench line, rocprofv3 kernel stats, per-kernel PMC averages."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", "profiles_" + tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
+# kernel stats: keep our kernels + the device primitives, drop torch fill/copy noise below 0.1 %
+rows = list(csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))))
+with open(os.path.join(dst, f"{tag}_rocprofv3_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=rows[0].keys())
+    w.writeheader()
+    for r in rows:
+        w.writerow(r)
+out = {}
+for name in ("pmc_sq", "pmc_tcc"):
+    p = os.path.join(src, name + "_counters.csv")
+    if not os.path.exists(p):
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(p)):
+        k = r["Kernel_Name"]
+        if "rg::" in k:
+            agg[k.split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        out.setdefault(k, {}).update({c: round(sum(x) / len(x)) for c, x in v.items()})
+for k, v in out.items():
+    if "TCC_EA0_RDREQ_sum" in v:
+        # FETCH/WRITE bytes as the microarch guide derives them: requests x 64 B (read side under-counts
+        # wide streaming reads by up to 2x on gfx950 -- MI355X_MICROARCH.md "HBM")
+        v["hbm_read_MB_64B_requests"] = round(v["TCC_EA0_RDREQ_sum"] * 64 / 1e6, 1)
+        v["hbm_write_MB_64B_requests"] = round(v["TCC_EA0_WRREQ_sum"] * 64 / 1e6, 1)
+json.dump(out, open(os.path.join(dst, f"{tag}_pmc_per_kernel.json"), "w"), indent=1, sort_keys=True)
+print(open(os.path.join(dst, f"{tag}_bench.json")).read()[:400])
+for r in rows[:14]:
+    print(r.get("Name", "")[:70], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage"))

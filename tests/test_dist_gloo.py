@@ -1,0 +1,72 @@
+"""world_size-2 gloo test of the view-parallel exchange step (rade-gs_amd/view_parallel.py): the one
+collective on the path is the bucketed all-reduce of the 59-float-per-Gaussian parameter gradients."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "rade-gs_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from view_parallel import allreduce_densification_stats, allreduce_gradients
+    P, M = 257, 16
+    g = torch.Generator().manual_seed(100 + rank)  # a different "view" per rank
+    grads = dict(dL_dmeans3D=torch.randn(P, 3, generator=g), dL_dsh=torch.randn(P, M, 3, generator=g),
+                 dL_dopacity=torch.randn(P, 1, generator=g), dL_dscales=torch.randn(P, 3, generator=g),
+                 dL_drotations=torch.randn(P, 4, generator=g), dL_dmeans2D=torch.randn(P, 3, generator=g))
+    red = allreduce_gradients(grads, average=True)
+    stats = allreduce_densification_stats(torch.full((P, 1), float(rank + 1)), torch.full((P, 1), 2.0 * (rank + 1)),
+                                          torch.ones(P), torch.arange(P, dtype=torch.int32) * (rank + 1))
+    torch.save({"red": red, "stats": stats}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_two_ranks(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
+    P, M = 257, 16
+    expect = {}
+    for r in range(world):
+        g = torch.Generator().manual_seed(100 + r)
+        for k, shape in (("dL_dmeans3D", (P, 3)), ("dL_dsh", (P, M, 3)), ("dL_dopacity", (P, 1)), ("dL_dscales", (P, 3)),
+                         ("dL_drotations", (P, 4)), ("dL_dmeans2D", (P, 3))):
+            t = torch.randn(*shape, generator=g)
+            expect.setdefault(k, []).append(t)
+    for r in range(world):
+        red = outs[r]["red"]
+        for k in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations"):
+            torch.testing.assert_close(red[k], (expect[k][0] + expect[k][1]) / world)
+        # the screen-space gradient is a per-view densification statistic, not a parameter gradient: untouched
+        torch.testing.assert_close(red["dL_dmeans2D"], expect["dL_dmeans2D"][r])
+        a, b, c, rad = outs[r]["stats"]
+        assert float(a[0]) == 3.0 and float(b[0]) == 6.0 and float(c[0]) == 2.0
+        assert rad.tolist() == (torch.arange(P, dtype=torch.int32) * 2).tolist()
+    # both ranks end with identical reduced gradients
+    for k in ("dL_dmeans3D", "dL_dsh"):
+        assert torch.equal(outs[0]["red"][k], outs[1]["red"][k])
+
+
+def test_single_process_is_a_noop():
+    sys.path.insert(0, os.path.join(ROOT, "rade-gs_amd"))
+    from view_parallel import allreduce_gradients
+    g = dict(dL_dmeans3D=torch.ones(4, 3))
+    assert allreduce_gradients(g)["dL_dmeans3D"] is g["dL_dmeans3D"]
