@@ -139,6 +139,26 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint32_t*
   if (i == L - 1) ranges[cur].y = L;
 }
 
+// Batch-level culling.  While a batch of 64 list entries is staged, lane k still has entry k's
+// record in registers; it tests the axis-aligned bounding box of the entry's {power >= thr} ellipse
+// (the only region where alpha can reach 1/255) against the pixel rectangle this wave owns.  One
+// ballot then gives the 64-bit set of entries worth visiting; the serial walk only touches those.
+// The ellipse  1/2 (cx dx^2 + 2 cy dx dy + cz dy^2) <= -thr  has half extents
+// hx = sqrt(m cz / det), hy = sqrt(m cx / det), m = -2 thr, det = cx cz - cy^2.  They are inflated by
+// 0.1 % + 0.01 px so fp32 rounding of `power` at a pixel can never disagree; any NaN makes the
+// comparisons false, i.e. keeps the entry (conservative).  thr > 0 (opacity so low that even the
+// centre fails) means the entry can never blend.
+__device__ __forceinline__ bool entry_may_touch(const float4 q0, const float4 q1, float x_lo, float x_hi, float y_lo, float y_hi) {
+  const float mx = q0.x, my = q0.y, cx = q0.z, cy = q0.w, cz = q1.x, thr = q1.z;
+  const float det = cx * cz - cy * cy;
+  const float m = -2.0f * thr;
+  const float r = m / det;
+  const float hx = sqrtf(r * cz) * 1.001f + 0.01f;
+  const float hy = sqrtf(r * cx) * 1.001f + 0.01f;
+  const bool off = (mx + hx < x_lo) || (mx - hx > x_hi) || (my + hy < y_lo) || (my - hy > y_hi) || (thr > 0.0f);
+  return !off;
+}
+
 // =========================================================================== blend, fwd ==
 struct BlendFwdArgs {
   const uint2* ranges; const uint32_t* point_list; const float4* splat_a; const float4* splat_b;
@@ -170,6 +190,9 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
   const int W = a.W, H = a.H;
   const size_t HW = (size_t)H * W;
   const float pixfx = (float)px;
+  // pixel rectangle owned by this wave (for batch culling)
+  const float reg_x0 = (float)(tile_x * 16), reg_x1 = reg_x0 + 15.0f;
+  const float reg_y0 = (float)(tile_y * 16 + sub * (4 * PPL)), reg_y1 = reg_y0 + (float)(4 * PPL - 1);
 
   const uint2 range = a.ranges[tile];
   const int n = (int)(range.y - range.x);
@@ -206,6 +229,7 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
     // ---- stage up to 64 list entries: one 64-B record (one cache line) per lane ----
     __syncthreads();
     const int k = base + lane;
+    bool rel_lane = false;
     if (k < n) {
       const uint32_t g = a.point_list[range.x + k];
       const float4* src = a.splat_a + 4 * (size_t)g;
@@ -215,14 +239,14 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
         const float4* sb = a.splat_b + 3 * (size_t)g;
         lds_b[lane * 3 + 0] = sb[0]; lds_b[lane * 3 + 1] = sb[1]; lds_b[lane * 3 + 2] = sb[2];
       }
+      rel_lane = entry_may_touch(q0, q1, reg_x0, reg_x1, reg_y0, reg_y1);
     }
+    uint64_t rel = __ballot(rel_lane);
     __syncthreads();
-    const int cnt = min(64, n - base);
-    float4 nA = lds_a[0], nB = lds_a[1];
-    for (int j = 0; j < cnt; j++) {
-      const float4 A = nA, B = nB;         // {mx,my,cx,cy} {cz,op,thr,ts}
-      nA = lds_a[(j + 1) * 4 + 0];         // prefetch next entry (slot 64 is padding)
-      nB = lds_a[(j + 1) * 4 + 1];
+    while (rel != 0 && !all_done) {
+      const int j = __builtin_ctzll(rel);
+      rel &= rel - 1;
+      const float4 A = lds_a[j * 4 + 0], B = lds_a[j * 4 + 1];  // {mx,my,cx,cy} {cz,op,thr,ts}
       const float dx = A.x - pixfx;
       const float a_x = (A.z * dx) * dx;
       const float b_xy = A.w * dx;
@@ -285,7 +309,6 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
 #pragma unroll
         for (int s = 0; s < PPL; s++) d = d && (Tw[s] == 0.0f);
         all_done = __all(d);
-        if (all_done) break;
       }
     }
   }
@@ -344,6 +367,7 @@ struct BlendBwdArgs {
   const float* dL_dpix; const float* dL_dcoord; const float* dL_dmcoord; const float* dL_ddepth; const float* dL_dmdepth;
   const float* dL_dalpha; const float* dL_dnormal;
   float* acc;  // [P][REC] per-Gaussian sums, SplatAcc order
+  int dbg;     // timing experiments only (RADEGS_BWD_DBG): 1 = no atomic, 2 = no reduce+atomic, 3 = no pair bodies
 };
 
 // In: v[i] = this lane's partial sum of component i.  Out (return value): the wave-wide total of
@@ -491,7 +515,6 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 2 : (PPL == 2 ? 3 : 5
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, m));
   const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-  const float inv_fx = 1.0f / a.focal_x, inv_fy = 1.0f / a.focal_y;
 
   for (int hi = (int)wave_last; hi > 0; hi -= 64) {
     __syncthreads();
@@ -535,11 +558,20 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 2 : (PPL == 2 ? 3 : 5
 #pragma unroll
       for (int i = 0; i < REC; i++) gv[i] = 0.f;
       bool contributed = false;
+      const float dxx = dx * dx;
 #pragma unroll
       for (int s = 0; s < PPL; s++) {
         if (cand[s]) {
-          const float G = exp_spec(power[s]);
-          const float alpha = fminf(0.99f, B.y * G);
+          // alpha.  The DECISION alpha < 1/255 must be the forward's (exp_spec); the VALUE may come from
+          // the hardware exp (3e-7 relative): only when op*exp is within 1e-4 of the threshold is the
+          // specified exponential evaluated, so the decision is always the exact one.
+          float G = __expf(power[s]);
+          float a_raw = B.y * G;
+          if (fabsf(fmaf(a_raw, 255.0f, -1.0f)) < 1.0e-4f) {
+            G = exp_spec(power[s]);
+            a_raw = B.y * G;
+          }
+          const float alpha = fminf(0.99f, a_raw);
           if (!(alpha < 1.0f / 255.0f)) {
             contributed = true;
             const float dy = A.y - pixfy[s];
@@ -548,13 +580,15 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 2 : (PPL == 2 ? 3 : 5
             T[s] = T[s] * inv1ma;
             const float dch = alpha * T[s];
             float dL_dopa = 0.f;
+            // "behind" accumulators: acc <- alpha*v + (1-alpha)*acc == acc + alpha*(v - acc)
             {
               const float col[3] = {C.x, C.y, C.z};
 #pragma unroll
               for (int c = 0; c < 3; c++) {
-                dL_dopa = fmaf(col[c] - accC[s][c], dLc[s][c], dL_dopa);
+                const float dd = col[c] - accC[s][c];
+                dL_dopa = fmaf(dd, dLc[s][c], dL_dopa);
                 gv[c] = fmaf(dch, dLc[s][c], gv[c]);
-                accC[s][c] = fmaf(alpha, col[c], one_m_a * accC[s][c]);
+                accC[s][c] = fmaf(alpha, dd, accC[s][c]);
               }
             }
             float dco[3] = {0.f, 0.f, 0.f}, dt_ = 0.f;
@@ -564,44 +598,49 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 2 : (PPL == 2 ? 3 : 5
 #pragma unroll
               for (int c = 0; c < 3; c++) {
                 const float cc = fmaf(cpy[c], dy, fmaf(cpx[c], dx, vp[c]));
-                dL_dopa = fmaf(cc - accCo[s][c], dLco[s][c], dL_dopa);
-                accCo[s][c] = fmaf(alpha, cc, one_m_a * accCo[s][c]);
+                const float dd = cc - accCo[s][c];
+                dL_dopa = fmaf(dd, dLco[s][c], dL_dopa);
+                accCo[s][c] = fmaf(alpha, dd, accCo[s][c]);
                 dco[c] = dch * dLco[s][c];
                 if (is_median) dco[c] += dLmco[s][c];
                 gv[16 + c] += dco[c];
-                gv[19 + 2 * c] = fmaf(dco[c] * dx, inv_fx, gv[19 + 2 * c]);
-                gv[20 + 2 * c] = fmaf(dco[c] * dy, inv_fy, gv[20 + 2 * c]);
+                gv[19 + 2 * c] = fmaf(dco[c], dx, gv[19 + 2 * c]);  // 1/focal applied per Gaussian later
+                gv[20 + 2 * c] = fmaf(dco[c], dy, gv[20 + 2 * c]);
               }
             }
             if constexpr (DEPTH) {
               const float t = B.w + fmaf(C.w, dx, Dq.x * dy);
-              dL_dopa = fmaf(t - accT[s], dLt[s], dL_dopa);
-              accT[s] = fmaf(alpha, t, one_m_a * accT[s]);
+              const float dd = t - accT[s];
+              dL_dopa = fmaf(dd, dLt[s], dL_dopa);
+              accT[s] = fmaf(alpha, dd, accT[s]);
               dt_ = dch * dLt[s];
               if (is_median) dt_ += dLmt[s];
               gv[3] += dt_;
-              gv[4] = fmaf(dt_ * dx, inv_fx, gv[4]);
-              gv[5] = fmaf(dt_ * dy, inv_fy, gv[5]);
+              gv[4] = fmaf(dt_, dx, gv[4]);  // 1/focal applied per Gaussian later
+              gv[5] = fmaf(dt_, dy, gv[5]);
             }
             if constexpr (NORMAL) {
               const float nn[3] = {Dq.y, Dq.z, Dq.w};
 #pragma unroll
               for (int c = 0; c < 3; c++) {
-                dL_dopa = fmaf(nn[c] - accN[s][c], dLn[s][c], dL_dopa);
+                const float dd = nn[c] - accN[s][c];
+                dL_dopa = fmaf(dd, dLn[s][c], dL_dopa);
                 gv[6 + c] = fmaf(dch, dLn[s][c], gv[6 + c]);
-                accN[s][c] = fmaf(alpha, nn[c], one_m_a * accN[s][c]);
+                accN[s][c] = fmaf(alpha, dd, accN[s][c]);
               }
             }
-            dL_dopa = fmaf(1 - acc_a[s], dLa[s], dL_dopa);
-            acc_a[s] = fmaf(one_m_a, acc_a[s], alpha);
+            const float da = 1.f - acc_a[s];
+            dL_dopa = fmaf(da, dLa[s], dL_dopa);
+            acc_a[s] = fmaf(alpha, da, acc_a[s]);
             dL_dopa *= T[s];
             dL_dopa = fmaf(inv1ma, tb[s], dL_dopa);
 
-            const float dL_dG = B.y * dL_dopa;
-            const float gdx = G * dx, gdy = G * dy;
-            const float dG_ddelx = -gdx * A.z - gdy * A.w;
-            const float dG_ddely = -gdy * B.x - gdx * A.w;
-            const float gx_ = dL_dG * dG_ddelx, gy_ = dL_dG * dG_ddely;
+            // d/d(mean2D, conic, opacity) through G = exp(power):  u = G*dL_dopa,  h = op*u = G*dL_dG
+            const float u = G * dL_dopa;
+            const float h = B.y * u;
+            const float ex = fmaf(dy, A.w, dx * A.z);   // dx*cx + dy*cy
+            const float ey = fmaf(dx, A.w, dy * B.x);   // dy*cz + dx*cy
+            const float gx_ = -h * ex, gy_ = -h * ey;   // dL_dG * dG_ddelx, dL_dG * dG_ddely
             float dL_ddelx = gx_, dL_ddely = gy_;
             if constexpr (COORD) {
               dL_ddelx += dco[0] * E0.x + dco[1] * E0.z + dco[2] * E1.x;
@@ -611,19 +650,290 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 2 : (PPL == 2 ? 3 : 5
               dL_ddelx = fmaf(dt_, C.w, dL_ddelx);
               dL_ddely = fmaf(dt_, Dq.x, dL_ddely);
             }
-            gv[9] = fmaf(dL_ddelx, ddelx_dx, gv[9]);
-            gv[10] = fmaf(dL_ddely, ddely_dy, gv[10]);
-            gv[11] += fabsf(gx_ * ddelx_dx) + fabsf(gy_ * ddely_dy);
-            gv[12] = fmaf(-0.5f * gdx * dx, dL_dG, gv[12]);
-            gv[13] = fmaf(-0.5f * gdx * dy, dL_dG, gv[13]);
-            gv[14] = fmaf(-0.5f * gdy * dy, dL_dG, gv[14]);
-            gv[15] = fmaf(G, dL_dopa, gv[15]);
+            gv[9] += dL_ddelx;    // x W/2, y H/2 applied per Gaussian later
+            gv[10] += dL_ddely;
+            gv[11] = fmaf(fabsf(gy_), ddely_dy, fmaf(fabsf(gx_), ddelx_dx, gv[11]));
+            const float hh = -0.5f * h;
+            gv[12] = fmaf(hh, dxx, gv[12]);
+            gv[13] = fmaf(hh, dx * dy, gv[13]);
+            gv[14] = fmaf(hh, dy * dy, gv[14]);
+            gv[15] += u;
           }
         }
       }
       if (!__any(contributed)) continue;
       const float tot = wave_reduce_scatter<REC, DPP>(gv, lane);
       if (lane < (COORD ? 25 : 16)) unsafeAtomicAdd(a.acc + (size_t)lds_id[j] * REC + lane, tot);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ blend, bwd (packed) ----
+// Second formulation of the same backward: the pixels of one lane are handled in PAIRS as 2-wide
+// fp32 vectors (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do two pixels per issue slot), and a
+// pixel that does not take part in an entry is switched off with two selects (alpha := 0, G := 0)
+// instead of a divergent branch: with alpha = 0 every recurrence below is an exact no-op
+// (T*rcp(1) = T, acc + 0*d = acc) and every gradient term is 0.  The only branches left are
+// wave-uniform, so the pair bodies are straight-line code the scheduler can interleave.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 bc2(float v) { return f2{v, v}; }
+
+template <bool COORD, bool DEPTH, int PPL>
+__global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 2 : 4))) blend_bwd_packed_kernel(const BlendBwdArgs a) {
+  static_assert(PPL == 2 || PPL == 4, "pairs of pixels per lane");
+  constexpr bool NORMAL = COORD || DEPTH;
+  constexpr int NP = PPL / 2;  // pairs per lane
+  constexpr int WPT = 4 / PPL;
+  constexpr int REC = COORD ? 32 : 16;
+  __shared__ float4 lds_a[65 * 4];
+  __shared__ float4 lds_b[COORD ? 64 * 3 : 1];
+  __shared__ uint32_t lds_id[65];
+
+  const int item = xcd_band_remap(blockIdx.x, gridDim.x);
+  const int tile = item / WPT, sub = item - tile * WPT;
+  const int tile_x = tile % a.gx, tile_y = tile / a.gx;
+  const int lane = threadIdx.x, lx = lane & 15, lr = lane >> 4;
+  const int px = tile_x * 16 + lx;
+  const int py0 = tile_y * 16 + sub * (4 * PPL) + lr;
+  const int W = a.W, H = a.H;
+  const size_t HW = (size_t)H * W;
+  const float pixfx = (float)px;
+  const float reg_x0 = (float)(tile_x * 16), reg_x1 = reg_x0 + 15.0f;
+  const float reg_y0 = (float)(tile_y * 16 + sub * (4 * PPL)), reg_y1 = reg_y0 + (float)(4 * PPL - 1);
+  const uint2 range = a.ranges[tile];
+
+  f2 pixfy[NP], T[NP], acc_a[NP], dLa[NP], tb[NP];
+  f2 dLc[NP][3], accC[NP][3];
+  f2 dLt[NP], dLmt[NP], accT[NP];
+  f2 dLn[NP][3], accN[NP][3];
+  f2 dLco[COORD ? NP : 1][3], dLmco[COORD ? NP : 1][3], accCo[COORD ? NP : 1][3];
+  uint32_t last_c[PPL], max_cm1[PPL];
+  uint32_t wave_last = 0;
+  const float pnx = (pixfx - W / 2.f) / a.focal_x;
+#pragma unroll
+  for (int s = 0; s < PPL; s++) {
+    const int q = s >> 1, e = s & 1;
+    const int py = py0 + 4 * s;
+    pixfy[q][e] = (float)py;
+    const bool inside = px < W && py < H;
+    const size_t pix = inside ? (size_t)W * py + px : 0;
+    const float alpha_px = inside ? a.alphas[pix] : 0.f;
+    const float T_final = inside ? (1 - alpha_px) : 0.f;
+    const float w_final = alpha_px;
+    T[q][e] = T_final;
+    last_c[s] = inside ? a.n_contrib[pix] : 0u;
+    max_cm1[s] = (inside ? a.n_contrib[pix + HW] : 0u) - 1u;
+    wave_last = max(wave_last, last_c[s]);
+    acc_a[q][e] = 0.f;
+    dLt[q][e] = 0.f; dLmt[q][e] = 0.f; accT[q][e] = 0.f;
+    float dl3[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      dl3[c] = inside ? a.dL_dpix[c * HW + pix] : 0.f;
+      dLc[q][c][e] = dl3[c];
+      accC[q][c][e] = 0.f;
+      dLn[q][c][e] = 0.f; accN[q][c][e] = 0.f;
+      if constexpr (COORD) { dLco[q][c][e] = 0.f; dLmco[q][c][e] = 0.f; accCo[q][c][e] = 0.f; }
+    }
+    float dla = inside ? a.dL_dalpha[pix] : 0.f;
+    tb[q][e] = -T_final * (a.bg[0] * dl3[0] + a.bg[1] * dl3[1] + a.bg[2] * dl3[2]);
+    if (NORMAL && inside) {
+      const float ww = w_final * w_final;
+      const float pny = ((float)py - H / 2.f) / a.focal_y;
+      const float ln = sqrtf(pnx * pnx + pny * pny + 1);
+      if constexpr (COORD) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const float gw = a.dL_dcoord[c * HW + pix];
+          dla -= gw * a.accum_coord[c * HW + pix] / ww;
+          dLco[q][c][e] = gw / w_final;
+          dLmco[q][c][e] = a.dL_dmcoord[c * HW + pix];
+        }
+      }
+      if constexpr (DEPTH) {
+        const float gw = a.dL_ddepth[pix];
+        dla -= gw * a.accum_depth[pix] / ww;
+        dLt[q][e] = gw / w_final / ln;
+        dLmt[q][e] = a.dL_dmdepth[pix] / ln;
+      }
+      {
+        const float g0 = a.dL_dnormal[pix], g1 = a.dL_dnormal[HW + pix], g2 = a.dL_dnormal[2 * HW + pix];
+        const float n0 = a.normalmap[pix], n1 = a.normalmap[HW + pix], n2 = a.normalmap[2 * HW + pix];
+        const float nlen = a.normal_length[pix];
+        if (nlen < 1.0E-12F) {
+          dLn[q][0][e] = g0 / 1.0E-12F; dLn[q][1][e] = g1 / 1.0E-12F; dLn[q][2][e] = g2 / 1.0E-12F;
+        } else {
+          const float dt = g0 * n0 + g1 * n1 + g2 * n2;
+          dLn[q][0][e] = (g0 - dt * n0) / nlen; dLn[q][1][e] = (g1 - dt * n1) / nlen; dLn[q][2][e] = (g2 - dt * n2) / nlen;
+        }
+      }
+    }
+    dLa[q][e] = dla;
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, m));
+  const f2 cW = bc2(0.5f * W), cH = bc2(0.5f * H);
+
+  for (int hi = (int)wave_last; hi > 0; hi -= 64) {
+    __syncthreads();
+    const int e0 = hi - 1 - lane;
+    bool rel_lane = false;
+    if (e0 >= 0) {
+      const uint32_t g = a.point_list[range.x + e0];
+      lds_id[lane] = g;
+      const float4* src = a.splat_a + 4 * (size_t)g;
+      const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+      lds_a[lane * 4 + 0] = q0; lds_a[lane * 4 + 1] = q1; lds_a[lane * 4 + 2] = q2; lds_a[lane * 4 + 3] = q3;
+      if constexpr (COORD) {
+        const float4* sb = a.splat_b + 3 * (size_t)g;
+        lds_b[lane * 3 + 0] = sb[0]; lds_b[lane * 3 + 1] = sb[1]; lds_b[lane * 3 + 2] = sb[2];
+      }
+      rel_lane = entry_may_touch(q0, q1, reg_x0, reg_x1, reg_y0, reg_y1);
+    }
+    uint64_t rel = __ballot(rel_lane);
+    __syncthreads();
+    while (rel != 0) {
+      const int j = __builtin_ctzll(rel);  // LDS slot j holds list position hi-1-j: ascending j = back to front
+      rel &= rel - 1;
+      const float4 A = lds_a[j * 4 + 0], B = lds_a[j * 4 + 1], C = lds_a[j * 4 + 2], Dq = lds_a[j * 4 + 3];
+      const uint32_t gid = lds_id[j];
+      const uint32_t pos = (uint32_t)(hi - 1 - j);
+      const float dx = A.x - pixfx;
+      const float a_x = (A.z * dx) * dx;
+      const float b_xy = A.w * dx;
+      f2 dy[NP], power[NP];
+      bool cand[PPL], anyc = false;
+#pragma unroll
+      for (int q = 0; q < NP; q++) {
+        dy[q] = bc2(A.y) - pixfy[q];
+        const f2 sq = bc2(a_x) + (bc2(B.x) * dy[q]) * dy[q];
+        const f2 vq = bc2(b_xy) * dy[q];
+        power[q] = fma2(bc2(-0.5f), sq, -vq);  // == splat_power(), one rounding (rg_blend.h)
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const float pw = power[q][e];
+          cand[2 * q + e] = (pos < last_c[2 * q + e]) && !(pw > 0.0f) && !(pw < B.z);
+          anyc = anyc || cand[2 * q + e];
+        }
+      }
+      if (!__any(anyc)) continue;
+      if (a.dbg == 3) { if (power[0][0] == 12345.f) a.acc[lane] = C.x + Dq.x + (float)gid; continue; }
+      float4 E0, E1, E2;
+      if constexpr (COORD) { E0 = lds_b[j * 3 + 0]; E1 = lds_b[j * 3 + 1]; E2 = lds_b[j * 3 + 2]; }
+      f2 gv[REC];
+#pragma unroll
+      for (int i = 0; i < REC; i++) gv[i] = bc2(0.f);
+      bool contributed = false;
+      const float dxx = dx * dx;
+#pragma unroll
+      for (int q = 0; q < NP; q++) {
+        if (!__any(cand[2 * q] || cand[2 * q + 1])) continue;  // wave-uniform
+        // ---- alpha (decision = forward's exp_spec rule; value from the hardware exp) ----
+        f2 G = f2{__expf(power[q][0]), __expf(power[q][1])};
+        f2 a_raw = bc2(B.y) * G;
+        {
+          const bool b0 = fabsf(fmaf(a_raw[0], 255.0f, -1.0f)) < 1.0e-4f, b1 = fabsf(fmaf(a_raw[1], 255.0f, -1.0f)) < 1.0e-4f;
+          if (__any(b0 || b1)) {  // within 1e-4 of the 1/255 threshold: decide with the specified exponential
+            if (b0) { G[0] = exp_spec(power[q][0]); a_raw[0] = B.y * G[0]; }
+            if (b1) { G[1] = exp_spec(power[q][1]); a_raw[1] = B.y * G[1]; }
+          }
+        }
+        f2 alpha = f2{fminf(0.99f, a_raw[0]), fminf(0.99f, a_raw[1])};
+        const bool act0 = cand[2 * q] && !(alpha[0] < 1.0f / 255.0f), act1 = cand[2 * q + 1] && !(alpha[1] < 1.0f / 255.0f);
+        contributed = contributed || act0 || act1;
+        alpha = f2{act0 ? alpha[0] : 0.f, act1 ? alpha[1] : 0.f};
+        G = f2{act0 ? G[0] : 0.f, act1 ? G[1] : 0.f};
+        const f2 one_m_a = bc2(1.f) - alpha;
+        const f2 inv1ma = f2{__builtin_amdgcn_rcpf(one_m_a[0]), __builtin_amdgcn_rcpf(one_m_a[1])};
+        T[q] = T[q] * inv1ma;
+        const f2 dch = alpha * T[q];
+        f2 dL_dopa = bc2(0.f);
+        {
+          const float col[3] = {C.x, C.y, C.z};
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const f2 dd = bc2(col[c]) - accC[q][c];
+            dL_dopa = fma2(dd, dLc[q][c], dL_dopa);
+            gv[c] = fma2(dch, dLc[q][c], gv[c]);
+            accC[q][c] = fma2(alpha, dd, accC[q][c]);
+          }
+        }
+        const bool med0 = act0 && pos == max_cm1[2 * q], med1 = act1 && pos == max_cm1[2 * q + 1];
+        f2 dco[3], dt_ = bc2(0.f);
+        if constexpr (COORD) {
+          const float cpx[3] = {E0.x, E0.z, E1.x}, cpy[3] = {E0.y, E0.w, E1.y}, vp[3] = {E1.z, E1.w, E2.x};
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const f2 cc = fma2(bc2(cpy[c]), dy[q], bc2(fmaf(cpx[c], dx, vp[c])));
+            const f2 dd = cc - accCo[q][c];
+            dL_dopa = fma2(dd, dLco[q][c], dL_dopa);
+            accCo[q][c] = fma2(alpha, dd, accCo[q][c]);
+            const f2 msel = f2{med0 ? dLmco[q][c][0] : 0.f, med1 ? dLmco[q][c][1] : 0.f};
+            dco[c] = fma2(dch, dLco[q][c], msel);
+            gv[16 + c] += dco[c];
+            gv[19 + 2 * c] = fma2(dco[c], bc2(dx), gv[19 + 2 * c]);
+            gv[20 + 2 * c] = fma2(dco[c], dy[q], gv[20 + 2 * c]);
+          }
+        }
+        if constexpr (DEPTH) {
+          const f2 t = fma2(bc2(Dq.x), dy[q], bc2(fmaf(C.w, dx, B.w)));
+          const f2 dd = t - accT[q];
+          dL_dopa = fma2(dd, dLt[q], dL_dopa);
+          accT[q] = fma2(alpha, dd, accT[q]);
+          const f2 msel = f2{med0 ? dLmt[q][0] : 0.f, med1 ? dLmt[q][1] : 0.f};
+          dt_ = fma2(dch, dLt[q], msel);
+          gv[3] += dt_;
+          gv[4] = fma2(dt_, bc2(dx), gv[4]);
+          gv[5] = fma2(dt_, dy[q], gv[5]);
+        }
+        if constexpr (NORMAL) {
+          const float nn[3] = {Dq.y, Dq.z, Dq.w};
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const f2 dd = bc2(nn[c]) - accN[q][c];
+            dL_dopa = fma2(dd, dLn[q][c], dL_dopa);
+            gv[6 + c] = fma2(dch, dLn[q][c], gv[6 + c]);
+            accN[q][c] = fma2(alpha, dd, accN[q][c]);
+          }
+        }
+        const f2 da = bc2(1.f) - acc_a[q];
+        dL_dopa = fma2(da, dLa[q], dL_dopa);
+        acc_a[q] = fma2(alpha, da, acc_a[q]);
+        dL_dopa = dL_dopa * T[q];
+        dL_dopa = fma2(inv1ma, tb[q], dL_dopa);
+
+        const f2 u = G * dL_dopa;
+        const f2 h = bc2(B.y) * u;
+        const f2 ex = fma2(dy[q], bc2(A.w), bc2(dx * A.z));
+        const f2 ey = fma2(dy[q], bc2(B.x), bc2(dx * A.w));
+        const f2 gx_ = -h * ex, gy_ = -h * ey;
+        f2 dL_ddelx = gx_, dL_ddely = gy_;
+        if constexpr (COORD) {
+          dL_ddelx = fma2(dco[0], bc2(E0.x), fma2(dco[1], bc2(E0.z), fma2(dco[2], bc2(E1.x), dL_ddelx)));
+          dL_ddely = fma2(dco[0], bc2(E0.y), fma2(dco[1], bc2(E0.w), fma2(dco[2], bc2(E1.y), dL_ddely)));
+        }
+        if constexpr (DEPTH) {
+          dL_ddelx = fma2(dt_, bc2(C.w), dL_ddelx);
+          dL_ddely = fma2(dt_, bc2(Dq.x), dL_ddely);
+        }
+        gv[9] += dL_ddelx;
+        gv[10] += dL_ddely;
+        gv[11] = fma2(__builtin_elementwise_abs(gy_), cH, fma2(__builtin_elementwise_abs(gx_), cW, gv[11]));
+        const f2 hh = bc2(-0.5f) * h;
+        gv[12] = fma2(hh, bc2(dxx), gv[12]);
+        gv[13] = fma2(hh, bc2(dx) * dy[q], gv[13]);
+        gv[14] = fma2(hh, dy[q] * dy[q], gv[14]);
+        gv[15] += u;
+      }
+      if (!__any(contributed)) continue;
+      if (a.dbg == 2) { if (gv[0][0] == 12345.f) a.acc[lane] = gv[1][1]; continue; }
+      float gs[REC];
+#pragma unroll
+      for (int i = 0; i < REC; i++) gs[i] = gv[i][0] + gv[i][1];
+      const float tot = wave_reduce_scatter<REC, true>(gs, lane);
+      if (a.dbg == 1) { if (tot == 12345.f) a.acc[lane] = tot; continue; }
+      if (lane < (COORD ? 25 : 16)) unsafeAtomicAdd(a.acc + (size_t)gid * REC + lane, tot);
     }
   }
 }
@@ -665,6 +975,15 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(const PreBwdArgs a)
 #pragma unroll
       for (int c = 16; c < 25; c++) dst[c] = 0.f;
     }
+  }
+  // constant factors the blend backward left out of its sums (linear, so they commute with the sum):
+  // 1/focal on the plane gradients (backward.cu:917-922,939-940), W/2 and H/2 on mean2D (:1002-1003)
+  {
+    const float ifx = 1.0f / cam.focal_x, ify = 1.0f / cam.focal_y;
+    acc.drp[0] *= ifx; acc.drp[1] *= ify;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { acc.dcp[2 * c] *= ifx; acc.dcp[2 * c + 1] *= ify; }
+    acc.dmean2D[0] *= 0.5f * cam.W; acc.dmean2D[1] *= 0.5f * cam.H;
   }
   const float* m = a.means3D + 3 * i;
   const float* sc = a.scales ? a.scales + 3 * i : nullptr;

@@ -12,7 +12,26 @@ seeded torch.Generator so that every rank / box sees identical inputs; move with
 import math
 from typing import NamedTuple, Optional
 
+import numpy as np
 import torch
+
+
+class _Rng:
+    """Seeded generator with torch-like calls.  numpy's PCG64 + ziggurat give the same stream on every
+    host; torch's CPU randn does not (its vectorised path depends on the CPU's ISA), which would make
+    fixtures generated in one container disagree with inputs regenerated on the GPU box."""
+
+    def __init__(self, seed):
+        self.g = np.random.default_rng(int(seed))
+
+    def randn(self, *shape):
+        return torch.from_numpy(self.g.standard_normal(shape, dtype=np.float64)).float()
+
+    def rand(self, *shape):
+        return torch.from_numpy(self.g.random(shape, dtype=np.float64)).float()
+
+    def randperm(self, n):
+        return torch.from_numpy(self.g.permutation(n))
 
 # BASELINE.json configs (SURVEY.md section 8): name -> (P, W, H, sh_degree, mu_px, mode, seed)
 CONFIGS = {
@@ -59,7 +78,7 @@ def projection_matrix(znear, zfar, fovx, fovy):
 
 
 def _rand_rotation(gen):
-    q = torch.randn(4, generator=gen)
+    q = gen.randn(4)
     q = q / q.norm()
     r, x, y, z = q.tolist()
     return torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)],
@@ -70,7 +89,7 @@ def _rand_rotation(gen):
 def make_scene(P, W, H, sh_degree=3, mu_px=1.5, seed=0, kernel_size=0.0, require_coord=False, require_depth=True,
                low_opacity=False, pose="identity", fovx_deg=60.0, bg=(0.0, 0.0, 0.0), near_cull_frac=0.02,
                filter3d=True) -> Scene:
-    gen = torch.Generator().manual_seed(int(seed))
+    gen = _Rng(seed)
     tanfovx = math.tan(math.radians(fovx_deg) * 0.5)
     tanfovy = tanfovx * H / W
     fovx, fovy = 2 * math.atan(tanfovx), 2 * math.atan(tanfovy)
@@ -81,7 +100,7 @@ def make_scene(P, W, H, sh_degree=3, mu_px=1.5, seed=0, kernel_size=0.0, require
         Rw2c, T = torch.eye(3), torch.zeros(3)
     else:
         Rw2c = _rand_rotation(gen)
-        T = torch.randn(3, generator=gen) * 0.5
+        T = gen.randn(3) * 0.5
     w2c = torch.eye(4)
     w2c[:3, :3] = Rw2c
     w2c[:3, 3] = T
@@ -91,13 +110,13 @@ def make_scene(P, W, H, sh_degree=3, mu_px=1.5, seed=0, kernel_size=0.0, require
     campos = torch.linalg.inv(viewmatrix)[3, :3].contiguous()          # scene/cameras.py:57
 
     def U(n, lo, hi):
-        return torch.rand(n, generator=gen) * (hi - lo) + lo
+        return gen.rand(n) * (hi - lo) + lo
 
     z = U(P, 2.0, 10.0)
     ncull = int(P * near_cull_frac)
     if ncull:
         z[:ncull] = U(ncull, -1.0, 0.2)
-        perm = torch.randperm(P, generator=gen)
+        perm = gen.randperm(P)
         z = z[perm]
     zz = z.abs().clamp_min(0.3)  # lateral extent also for culled points
     x = zz * tanfovx * U(P, -1.1, 1.1)
@@ -105,13 +124,13 @@ def make_scene(P, W, H, sh_degree=3, mu_px=1.5, seed=0, kernel_size=0.0, require
     cam_pts = torch.stack([x, y, z], 1)
     means3D = (cam_pts - T) @ Rw2c  # = Rw2c^T (p - T), row-vector form
 
-    sigma_px = torch.exp(math.log(mu_px) + 0.6 * torch.randn(P, generator=gen))
-    aniso = torch.exp(0.5 * torch.randn(P, 3, generator=gen))
+    sigma_px = torch.exp(math.log(mu_px) + 0.6 * gen.randn(P))
+    aniso = torch.exp(0.5 * gen.randn(P, 3))
     scales = (zz * sigma_px / focal_x)[:, None] * aniso
     if low_opacity:
         opacity = U(P, 0.02, 0.3)[:, None]
     else:
-        opacity = torch.sigmoid(2.0 * torch.randn(P, 1, generator=gen))
+        opacity = torch.sigmoid(2.0 * gen.randn(P, 1))
     if filter3d:  # scene/gaussian_model.py:156-166 with filter_3D = z/focal * sqrt(0.2)
         filt = (zz / focal_x * math.sqrt(0.2))[:, None]
         s2 = scales * scales
@@ -120,9 +139,9 @@ def make_scene(P, W, H, sh_degree=3, mu_px=1.5, seed=0, kernel_size=0.0, require
         det2 = s2f.prod(1)
         opacity = opacity * torch.sqrt(det1 / det2)[:, None]
         scales = torch.sqrt(s2f)
-    q = torch.randn(P, 4, generator=gen)
+    q = gen.randn(P, 4)
     rotations = q / q.norm(dim=1, keepdim=True)
-    shs = torch.cat([torch.randn(P, 1, 3, generator=gen), 0.1 * torch.randn(P, 15, 3, generator=gen)], 1)
+    shs = torch.cat([gen.randn(P, 1, 3), 0.1 * gen.randn(P, 15, 3)], 1)
     return Scene(means3D.float().contiguous(), opacity.float().contiguous(), scales.float().contiguous(),
                  rotations.float().contiguous(), shs.float().contiguous(), viewmatrix.float(), projmatrix.float(),
                  campos.float(), torch.tensor(bg, dtype=torch.float32), tanfovx, tanfovy, W, H, sh_degree,
@@ -137,11 +156,11 @@ def make_config(name, **over) -> Scene:
 
 def upstream_grads(scene: Scene, seed=0):
     """Fixed random cotangents w_k for the 7 image outputs (loss = sum_k <w_k, out_k>)."""
-    gen = torch.Generator().manual_seed(10_000 + int(seed))
+    gen = _Rng(10_000 + int(seed))
     H, W = scene.H, scene.W
 
     def n(c):
-        return torch.randn(c, H, W, generator=gen)
+        return gen.randn(c, H, W)
 
     g = dict(color=n(3), coord=n(3), mcoord=n(3), depth=n(1), mdepth=n(1), alpha=n(1), normal=n(3))
     if not scene.require_coord:

@@ -83,6 +83,12 @@ def check_backward(s, o, colors=None, cov3D=None, seed=0, ill_mask=None):
                               o.get("dL_dnormals", (P, 3)), o.get("acc_dmeans2D", (P, 3)), dc[:, [0, 1, 3]],
                               o.get("acc_dopacity", (P, 1)), o.get("dL_dview_points", (P, 3)), o.get("dL_dcamera_planes", (P, 6))], 1)
     vis = o.get("radii") > 0
+    # the kernel leaves constant factors to the per-Gaussian stage: 1/focal on plane sums, W/2, H/2 on mean2D
+    fx, fy = s.W / (2 * s.tanfovx), s.H / (2 * s.tanfovy)
+    acc = acc.astype(np.float64)
+    acc[:, 4] /= fx; acc[:, 5] /= fy; acc[:, 9] *= 0.5 * s.W; acc[:, 10] *= 0.5 * s.H
+    if rec == 32:
+        acc[:, 19:25:2] /= fx; acc[:, 20:25:2] /= fy
     for c in range(rec if rec == 16 else 25):
         a, b = acc[vis, c], ref_acc[vis, c]
         scale = float(np.abs(b).max()) + 1e-30
@@ -181,7 +187,7 @@ def test_mark_visible():
     assert np.array_equal(got, orc.mark_visible(s.means3D, s.viewmatrix, s.projmatrix))
 
 
-@pytest.mark.parametrize("fwd_ppl,bwd_ppl", [(1, 1), (2, 4), (4, 2)])
+@pytest.mark.parametrize("fwd_ppl,bwd_ppl", [(1, 2), (2, 4), (4, 2)])
 def test_pixels_per_lane_variants_agree(fwd_ppl, bwd_ppl, monkeypatch):
     monkeypatch.setenv("RADEGS_FWD_PPL", str(fwd_ppl))
     monkeypatch.setenv("RADEGS_BWD_PPL", str(bwd_ppl))
