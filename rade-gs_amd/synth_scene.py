@@ -17,21 +17,23 @@ import torch
 
 
 class _Rng:
-    """Seeded generator with torch-like calls.  numpy's PCG64 + ziggurat give the same stream on every
-    host; torch's CPU randn does not (its vectorised path depends on the CPU's ISA), which would make
-    fixtures generated in one container disagree with inputs regenerated on the GPU box."""
+    """Seeded float64 numpy streams (PCG64 + ziggurat: the same on every host).  All scene math below is
+    done in float64 with numpy and rounded to float32 ONCE at the end, so the generated inputs are
+    bit-identical on every machine; torch's CPU randn/exp/sigmoid are vectorised per ISA and differ in
+    the last bit between hosts, which would make committed fixtures disagree with regenerated inputs."""
 
     def __init__(self, seed):
         self.g = np.random.default_rng(int(seed))
 
     def randn(self, *shape):
-        return torch.from_numpy(self.g.standard_normal(shape, dtype=np.float64)).float()
+        return self.g.standard_normal(shape, dtype=np.float64)
 
     def rand(self, *shape):
-        return torch.from_numpy(self.g.random(shape, dtype=np.float64)).float()
+        return self.g.random(shape, dtype=np.float64)
 
     def randperm(self, n):
-        return torch.from_numpy(self.g.permutation(n))
+        return self.g.permutation(n)
+
 
 # BASELINE.json configs (SURVEY.md section 8): name -> (P, W, H, sh_degree, mu_px, mode, seed)
 CONFIGS = {
@@ -65,10 +67,10 @@ class Scene(NamedTuple):
 
 
 def projection_matrix(znear, zfar, fovx, fovy):
-    """utils/graphics_utils.py:67-87 (returned un-transposed, like the reference)."""
+    """utils/graphics_utils.py:67-87 (returned un-transposed, like the reference); float64 numpy."""
     t = math.tan(fovy / 2) * znear
     r = math.tan(fovx / 2) * znear
-    P = torch.zeros(4, 4)
+    P = np.zeros((4, 4))
     P[0, 0] = 2.0 * znear / (2 * r)
     P[1, 1] = 2.0 * znear / (2 * t)
     P[3, 2] = 1.0
@@ -79,11 +81,14 @@ def projection_matrix(znear, zfar, fovx, fovy):
 
 def _rand_rotation(gen):
     q = gen.randn(4)
-    q = q / q.norm()
-    r, x, y, z = q.tolist()
-    return torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)],
-                         [2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)],
-                         [2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]])
+    r, x, y, z = (q / np.linalg.norm(q)).tolist()
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)],
+                     [2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)],
+                     [2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]])
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
 
 
 def make_scene(P, W, H, sh_degree=3, mu_px=1.5, seed=0, kernel_size=0.0, require_coord=False, require_depth=True,
@@ -97,17 +102,17 @@ def make_scene(P, W, H, sh_degree=3, mu_px=1.5, seed=0, kernel_size=0.0, require
 
     # camera pose: world->view rotation Rw2c and translation T (view = Rw2c @ x + T)
     if pose == "identity":
-        Rw2c, T = torch.eye(3), torch.zeros(3)
+        Rw2c, T = np.eye(3), np.zeros(3)
     else:
         Rw2c = _rand_rotation(gen)
         T = gen.randn(3) * 0.5
-    w2c = torch.eye(4)
+    w2c = np.eye(4)
     w2c[:3, :3] = Rw2c
     w2c[:3, 3] = T
-    viewmatrix = w2c.transpose(0, 1).contiguous()                      # scene/cameras.py:54
-    proj = projection_matrix(0.01, 100.0, fovx, fovy).transpose(0, 1)  # scene/cameras.py:55
-    projmatrix = (viewmatrix @ proj).contiguous()                      # scene/cameras.py:56
-    campos = torch.linalg.inv(viewmatrix)[3, :3].contiguous()          # scene/cameras.py:57
+    viewmatrix = w2c.T.copy()                                    # scene/cameras.py:54 (stored transposed)
+    proj = projection_matrix(0.01, 100.0, fovx, fovy).T          # scene/cameras.py:55
+    projmatrix = viewmatrix @ proj                               # scene/cameras.py:56
+    campos = np.linalg.inv(viewmatrix)[3, :3]                    # scene/cameras.py:57
 
     def U(n, lo, hi):
         return gen.rand(n) * (hi - lo) + lo
@@ -116,36 +121,34 @@ def make_scene(P, W, H, sh_degree=3, mu_px=1.5, seed=0, kernel_size=0.0, require
     ncull = int(P * near_cull_frac)
     if ncull:
         z[:ncull] = U(ncull, -1.0, 0.2)
-        perm = gen.randperm(P)
-        z = z[perm]
-    zz = z.abs().clamp_min(0.3)  # lateral extent also for culled points
+        z = z[gen.randperm(P)]
+    zz = np.maximum(np.abs(z), 0.3)  # lateral extent also for culled points
     x = zz * tanfovx * U(P, -1.1, 1.1)
     y = zz * tanfovy * U(P, -1.1, 1.1)
-    cam_pts = torch.stack([x, y, z], 1)
+    cam_pts = np.stack([x, y, z], 1)
     means3D = (cam_pts - T) @ Rw2c  # = Rw2c^T (p - T), row-vector form
 
-    sigma_px = torch.exp(math.log(mu_px) + 0.6 * gen.randn(P))
-    aniso = torch.exp(0.5 * gen.randn(P, 3))
+    sigma_px = np.exp(math.log(mu_px) + 0.6 * gen.randn(P))
+    aniso = np.exp(0.5 * gen.randn(P, 3))
     scales = (zz * sigma_px / focal_x)[:, None] * aniso
     if low_opacity:
         opacity = U(P, 0.02, 0.3)[:, None]
     else:
-        opacity = torch.sigmoid(2.0 * gen.randn(P, 1))
+        opacity = 1.0 / (1.0 + np.exp(-2.0 * gen.randn(P, 1)))
     if filter3d:  # scene/gaussian_model.py:156-166 with filter_3D = z/focal * sqrt(0.2)
         filt = (zz / focal_x * math.sqrt(0.2))[:, None]
         s2 = scales * scales
         det1 = s2.prod(1)
         s2f = s2 + filt * filt
         det2 = s2f.prod(1)
-        opacity = opacity * torch.sqrt(det1 / det2)[:, None]
-        scales = torch.sqrt(s2f)
+        opacity = opacity * np.sqrt(det1 / det2)[:, None]
+        scales = np.sqrt(s2f)
     q = gen.randn(P, 4)
-    rotations = q / q.norm(dim=1, keepdim=True)
-    shs = torch.cat([gen.randn(P, 1, 3), 0.1 * gen.randn(P, 15, 3)], 1)
-    return Scene(means3D.float().contiguous(), opacity.float().contiguous(), scales.float().contiguous(),
-                 rotations.float().contiguous(), shs.float().contiguous(), viewmatrix.float(), projmatrix.float(),
-                 campos.float(), torch.tensor(bg, dtype=torch.float32), tanfovx, tanfovy, W, H, sh_degree,
-                 float(kernel_size), bool(require_coord), bool(require_depth))
+    rotations = q / np.linalg.norm(q, axis=1, keepdims=True)
+    shs = np.concatenate([gen.randn(P, 1, 3), 0.1 * gen.randn(P, 15, 3)], 1)
+    return Scene(_t(means3D), _t(opacity), _t(scales), _t(rotations), _t(shs), _t(viewmatrix), _t(projmatrix), _t(campos),
+                 torch.tensor(bg, dtype=torch.float32), tanfovx, tanfovy, W, H, sh_degree, float(kernel_size), bool(require_coord),
+                 bool(require_depth))
 
 
 def make_config(name, **over) -> Scene:
@@ -160,7 +163,7 @@ def upstream_grads(scene: Scene, seed=0):
     H, W = scene.H, scene.W
 
     def n(c):
-        return gen.randn(c, H, W)
+        return _t(gen.randn(c, H, W))
 
     g = dict(color=n(3), coord=n(3), mcoord=n(3), depth=n(1), mdepth=n(1), alpha=n(1), normal=n(3))
     if not scene.require_coord:

@@ -17,7 +17,7 @@ for p in (ROOT, os.path.join(ROOT, "rade-gs_amd"), os.path.join(ROOT, "tests")):
 import numpy as np  # noqa: E402
 
 from synth_scene import make_scene, upstream_grads  # noqa: E402
-from util import oracle_backward, oracle_for  # noqa: E402
+from util import grad_noise_floor, oracle_backward, oracle_for  # noqa: E402
 
 CASES = {
     "g_depth": dict(P=400, W=64, H=48, sh_degree=3, mu_px=3.0, seed=101, kernel_size=0.1, require_coord=False, require_depth=True, pose="random"),
@@ -31,11 +31,15 @@ def run(case):
     o = oracle_for(s, nthreads=1)
     R = o.forward()
     out = o.outputs()
-    gr = oracle_backward(o, upstream_grads(s, CASES[case]["seed"]))
+    g = upstream_grads(s, CASES[case]["seed"])
+    gr = oracle_backward(o, g)
+    floor, _ = grad_noise_floor(s, g)  # |fp32 - fp64| of the oracle: the fp32 conditioning of each gradient
     d = dict(num_rendered=np.int64(R), radii=out[1], point_list=o.get("point_list"), ranges=o.get("ranges"), n_contrib=o.get("n_contrib"))
     for k, i in (("color", 0), ("coord", 2), ("mcoord", 3), ("depth", 4), ("mdepth", 5), ("alpha", 6), ("normal", 7)):
         d[k] = out[i]
     d.update(gr)
+    for k, v in floor.items():
+        d["floor_" + k] = np.float64(v)
     return d
 
 

@@ -19,7 +19,9 @@ def test_oracle_reproduces_golden(case):
     got = make_golden.run(case)
     for k in want.files:
         a, b = np.asarray(got[k]), want[k]
-        if a.dtype.kind == "f":
+        if k.startswith("floor_"):
+            assert abs(float(a) - float(b)) <= 1e-3 * float(b) + 1e-12, k
+        elif a.dtype.kind == "f":
             # -ffp-contract=off + IEEE ops: identical across x86-64 hosts; double accumulators of the
             # blend backward are order-independent to well below one fp32 ulp
             assert np.allclose(a, b, rtol=1e-6, atol=1e-7), k
@@ -52,4 +54,5 @@ def test_hip_matches_golden(case):
     for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dsh", "dL_dscales", "dL_drotations"):
         b = want[k].reshape(got[k].shape)
         scale = float(np.abs(b).max()) + 1e-30
-        assert close(got[k], b, atol=ATOL + 2e-6 * scale, rtol=1e-3).all(), k
+        band = ATOL + max(2e-6 * scale, 0.25 * float(want["floor_" + k]))  # see util.grad_noise_floor
+        assert close(got[k], b, atol=band, rtol=1e-3).all(), k

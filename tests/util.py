@@ -51,3 +51,20 @@ def cov3d_of(s: Scene):
                      2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
     Sg = R @ torch.diag_embed(sc * sc) @ R.transpose(1, 2)
     return torch.stack([Sg[:, 0, 0], Sg[:, 0, 1], Sg[:, 0, 2], Sg[:, 1, 1], Sg[:, 1, 2], Sg[:, 2, 2]], 1).float().contiguous()
+
+
+def grad_noise_floor(scene, g, colors=None, cov3D=None):
+    """fp32 conditioning of the backward.  The algorithm itself (reference arithmetic: T recovered by
+    repeated division, differences of nearly equal blended values, sums of +/- terms) is only accurate to
+    ~1e-3 relative in fp32 -- measured as |oracle_fp32 - oracle_fp64| per gradient tensor.  Two correct fp32
+    implementations that round differently (fma vs mul+add, hardware exp/rcp) can therefore differ by a
+    fraction of this floor even when both are as close to the exact gradient as fp32 allows.
+    Returns {name: max |fp32 - fp64|} or None if the fp64 run took different thresholded decisions."""
+    o32 = oracle_for(scene, colors=colors, cov3D=cov3D, nthreads=1)
+    o32.forward()
+    o64 = oracle_for(scene, precision=64, colors=colors, cov3D=cov3D, nthreads=1)
+    o64.forward()
+    if not (np.array_equal(o32.get("n_contrib"), o64.get("n_contrib")) and np.array_equal(o32.get("point_list"), o64.get("point_list"))):
+        return None
+    g32, g64 = oracle_backward(o32, g), oracle_backward(o64, g)
+    return {k: float(np.abs(g32[k].astype(np.float64) - g64[k]).max()) if g32[k].size else 0.0 for k in g32}, g64
