@@ -948,71 +948,114 @@ struct PreBwdArgs {
   float* dL_drot;
 };
 
-__global__ void __launch_bounds__(256) preprocess_bwd_kernel(const PreBwdArgs a) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= a.P) return;
-  const size_t i = (size_t)idx;
-  float* dsh = a.dL_dsh ? a.dL_dsh + i * a.M * 3 : nullptr;
-  if (!(a.radii[idx] > 0)) {  // invisible: every returned row is zero (rasterize_points.cu:180-193)
-    for (int c = 0; c < 3; c++) { a.dL_dmean2D[3 * i + c] = 0; a.dL_dcolor[3 * i + c] = 0; a.dL_dmean3D[3 * i + c] = 0; a.dL_dscale[3 * i + c] = 0; }
-    a.dL_dopacity[i] = 0;
-    for (int c = 0; c < 6; c++) a.dL_dcov3D[6 * i + c] = 0;
-    for (int c = 0; c < 4; c++) a.dL_drot[4 * i + c] = 0;
-    if (dsh) for (int c = 0; c < a.M * 3; c++) dsh[c] = 0;
-    return;
+// 128 Gaussians per block.  The (P,M,3) SH tensor and its gradient are 192-byte rows at SH degree 3: read or
+// written by one thread each they would be 64 different cache lines per instruction.  The block therefore
+// moves its contiguous 128-row slab with coalesced accesses through LDS (row stride 3M+1 words: odd, so the
+// per-thread row walks are bank-conflict free); sh and dL/dsh share the slab (sh_bwd's access order allows it).
+constexpr int kPreBwdThreads = 128;
+__global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const PreBwdArgs a) {
+  extern __shared__ float sh_slab[];  // [128][3M+1]
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * kPreBwdThreads;
+  const int idx = base + tid;
+  const int nrows = min(kPreBwdThreads, a.P - base);
+  const int rowf = a.M * 3, stride = rowf + 1;
+  const bool have_sh = a.shs != nullptr;
+  if (have_sh) {
+    const float* src = a.shs + (size_t)base * rowf;
+    for (int e = tid; e < nrows * rowf; e += kPreBwdThreads) {
+      const int g = e / rowf, c = e - g * rowf;
+      sh_slab[g * stride + c] = src[e];
+    }
+    __syncthreads();
   }
-  const Camera cam = load_camera(a.cam);
-  SplatAcc acc;
-  {
-    const float* r = a.acc + i * a.rec;
-    float* dst = reinterpret_cast<float*>(&acc);
+  if (idx < a.P) {
+    const size_t i = (size_t)idx;
+    float* row = have_sh ? sh_slab + tid * stride : nullptr;
+    if (!(a.radii[idx] > 0)) {  // invisible: every returned row is zero (rasterize_points.cu:180-193)
 #pragma unroll
-    for (int c = 0; c < 16; c++) dst[c] = r[c];
-    if (a.rec == 32) {
+      for (int c = 0; c < 3; c++) { a.dL_dmean2D[3 * i + c] = 0; a.dL_dcolor[3 * i + c] = 0; a.dL_dmean3D[3 * i + c] = 0; a.dL_dscale[3 * i + c] = 0; }
+      a.dL_dopacity[i] = 0;
 #pragma unroll
-      for (int c = 16; c < 25; c++) dst[c] = r[c];
+      for (int c = 0; c < 6; c++) a.dL_dcov3D[6 * i + c] = 0;
+#pragma unroll
+      for (int c = 0; c < 4; c++) a.dL_drot[4 * i + c] = 0;
+      if (row) for (int c = 0; c < rowf; c++) row[c] = 0;
     } else {
+      const Camera cam = load_camera(a.cam);
+      SplatAcc acc;
+      {
+        const float4* r = reinterpret_cast<const float4*>(a.acc + i * a.rec);
+        const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+        acc.dcolor[0] = r0.x; acc.dcolor[1] = r0.y; acc.dcolor[2] = r0.z; acc.dts = r0.w;
+        acc.drp[0] = r1.x; acc.drp[1] = r1.y; acc.dnrm[0] = r1.z; acc.dnrm[1] = r1.w;
+        acc.dnrm[2] = r2.x; acc.dmean2D[0] = r2.y; acc.dmean2D[1] = r2.z; acc.dmean2D[2] = r2.w;
+        acc.dconic[0] = r3.x; acc.dconic[1] = r3.y; acc.dconic[2] = r3.z; acc.dop = r3.w;
+        if (a.rec == 32) {
+          const float4 r4 = r[4], r5 = r[5];
+          const float r6 = r[6].x;
+          acc.dvp[0] = r4.x; acc.dvp[1] = r4.y; acc.dvp[2] = r4.z; acc.dcp[0] = r4.w;
+          acc.dcp[1] = r5.x; acc.dcp[2] = r5.y; acc.dcp[3] = r5.z; acc.dcp[4] = r5.w; acc.dcp[5] = r6;
+        } else {
+          acc.dvp[0] = acc.dvp[1] = acc.dvp[2] = 0.f;
 #pragma unroll
-      for (int c = 16; c < 25; c++) dst[c] = 0.f;
+          for (int c = 0; c < 6; c++) acc.dcp[c] = 0.f;
+        }
+      }
+      // constant factors the blend backward left out of its sums (linear, so they commute with the sum):
+      // 1/focal on the plane gradients (backward.cu:917-922,939-940), W/2 and H/2 on mean2D (:1002-1003)
+      {
+        const float ifx = 1.0f / cam.focal_x, ify = 1.0f / cam.focal_y;
+        acc.drp[0] *= ifx; acc.drp[1] *= ify;
+#pragma unroll
+        for (int c = 0; c < 3; c++) { acc.dcp[2 * c] *= ifx; acc.dcp[2 * c + 1] *= ify; }
+        acc.dmean2D[0] *= 0.5f * cam.W; acc.dmean2D[1] *= 0.5f * cam.H;
+      }
+      const float* m = a.means3D + 3 * i;
+      float sc3[3], rq4[4];
+      const bool has_sr = a.scales != nullptr;
+      if (has_sr) {
+        sc3[0] = a.scales[3 * i]; sc3[1] = a.scales[3 * i + 1]; sc3[2] = a.scales[3 * i + 2];
+        const float4 q = *reinterpret_cast<const float4*>(a.rotations + 4 * i);
+        rq4[0] = q.x; rq4[1] = q.y; rq4[2] = q.z; rq4[3] = q.w;
+      }
+      float cov[6];
+      if (a.cov3D_precomp) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) cov[c] = a.cov3D_precomp[6 * i + c];
+      } else {
+        cov3d_from_scale_rot(sc3, cam.scale_modifier, rq4, cov);
+      }
+      const float op_combined = a.splat_a[4 * i + 1].y;
+      if (row) {  // rows beyond the active degree stay zero
+        const int K = (a.D + 1) * (a.D + 1);
+        for (int c = K * 3; c < rowf; c++) row[c] = 0;
+      }
+      SplatBwd o;
+      o.dscale[0] = o.dscale[1] = o.dscale[2] = 0; o.drot[0] = o.drot[1] = o.drot[2] = o.drot[3] = 0;
+      preprocess_bwd(mk3(m[0], m[1], m[2]), has_sr ? sc3 : nullptr, has_sr ? rq4 : nullptr, cov, op_combined, a.D, row,
+                     (unsigned)a.clamped[idx], cam, acc, row, o);
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        a.dL_dmean2D[3 * i + c] = acc.dmean2D[c];
+        a.dL_dcolor[3 * i + c] = acc.dcolor[c];
+        a.dL_dmean3D[3 * i + c] = o.dmean3D[c];
+        a.dL_dscale[3 * i + c] = o.dscale[c];
+      }
+      a.dL_dopacity[i] = o.dopacity;
+#pragma unroll
+      for (int c = 0; c < 6; c++) a.dL_dcov3D[6 * i + c] = o.dcov3D[c];
+      *reinterpret_cast<float4*>(a.dL_drot + 4 * i) = make_float4(o.drot[0], o.drot[1], o.drot[2], o.drot[3]);
     }
   }
-  // constant factors the blend backward left out of its sums (linear, so they commute with the sum):
-  // 1/focal on the plane gradients (backward.cu:917-922,939-940), W/2 and H/2 on mean2D (:1002-1003)
-  {
-    const float ifx = 1.0f / cam.focal_x, ify = 1.0f / cam.focal_y;
-    acc.drp[0] *= ifx; acc.drp[1] *= ify;
-#pragma unroll
-    for (int c = 0; c < 3; c++) { acc.dcp[2 * c] *= ifx; acc.dcp[2 * c + 1] *= ify; }
-    acc.dmean2D[0] *= 0.5f * cam.W; acc.dmean2D[1] *= 0.5f * cam.H;
+  if (have_sh) {
+    __syncthreads();
+    float* dst = a.dL_dsh + (size_t)base * rowf;
+    for (int e = tid; e < nrows * rowf; e += kPreBwdThreads) {
+      const int g = e / rowf, c = e - g * rowf;
+      dst[e] = sh_slab[g * stride + c];
+    }
   }
-  const float* m = a.means3D + 3 * i;
-  const float* sc = a.scales ? a.scales + 3 * i : nullptr;
-  const float* rq = a.rotations ? a.rotations + 4 * i : nullptr;
-  float cov[6];
-  if (a.cov3D_precomp) {
-#pragma unroll
-    for (int c = 0; c < 6; c++) cov[c] = a.cov3D_precomp[6 * i + c];
-  } else {
-    cov3d_from_scale_rot(sc, cam.scale_modifier, rq, cov);
-  }
-  const float op_combined = a.splat_a[4 * i + 1].y;
-  const float* sh = a.shs ? a.shs + i * a.M * 3 : nullptr;
-  if (dsh) {  // rows beyond the active degree stay zero
-    const int K = (a.D + 1) * (a.D + 1);
-    for (int c = K * 3; c < a.M * 3; c++) dsh[c] = 0;
-  }
-  SplatBwd o;
-  o.dscale[0] = o.dscale[1] = o.dscale[2] = 0; o.drot[0] = o.drot[1] = o.drot[2] = o.drot[3] = 0;
-  preprocess_bwd(mk3(m[0], m[1], m[2]), sc, rq, cov, op_combined, a.D, sh, (unsigned)a.clamped[idx], cam, acc, dsh, o);
-  for (int c = 0; c < 3; c++) {
-    a.dL_dmean2D[3 * i + c] = acc.dmean2D[c];
-    a.dL_dcolor[3 * i + c] = acc.dcolor[c];
-    a.dL_dmean3D[3 * i + c] = o.dmean3D[c];
-    a.dL_dscale[3 * i + c] = o.dscale[c];
-  }
-  a.dL_dopacity[i] = o.dopacity;
-  for (int c = 0; c < 6; c++) a.dL_dcov3D[6 * i + c] = o.dcov3D[c];
-  for (int c = 0; c < 4; c++) a.dL_drot[4 * i + c] = o.drot[c];
 }
 
 }  // namespace rg

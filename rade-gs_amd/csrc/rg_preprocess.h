@@ -115,7 +115,8 @@ RG_HD void cov2d_common(v3 mean, const Camera& cam, const float cov3D[6], Cov2D&
     m3 dg = mk33(1 / e0, 0, 0, 0, 1 / e1, 0, 0, 0, 1 / e2);
     o.Vinv = mul(mul(V, dg), transpose(V));
   } else {
-    o.evmin = col(V, o.min_id);
+    // select chain instead of a dynamic column index: keeps V in registers (no scratch / LDS promotion)
+    o.evmin = o.min_id == 0 ? col(V, 0) : (o.min_id == 1 ? col(V, 1) : col(V, 2));
     o.Vinv = outer(o.evmin, o.evmin);
   }
   o.cam_inv = mul(mul(transpose(o.W), o.Vinv), o.W);

@@ -61,23 +61,23 @@ RG_HD v3 sh_bwd(int deg, const float* sh, v3 pos, const float campos[3], unsigne
     v3 tv = mul((wgt), dRGB);                        \
     dsh[3 * (k)] = tv.x; dsh[3 * (k) + 1] = tv.y; dsh[3 * (k) + 2] = tv.z; \
   }
+  // Ordering note: inside every degree block all reads of sh[] come BEFORE the writes of dsh[] for the
+  // same coefficients, so sh and dsh may alias (the kernel stages both through one LDS row).  The
+  // statements are independent, so this order changes no value.
   PUT(0, RG_C0);
   if (deg > 0) {
-    PUT(1, -RG_C1 * y); PUT(2, RG_C1 * z); PUT(3, -RG_C1 * x);
     dx = mul(-RG_C1, SH(3));
     dy = mul(-RG_C1, SH(1));
     dz = mul(RG_C1, SH(2));
+    PUT(1, -RG_C1 * y); PUT(2, RG_C1 * z); PUT(3, -RG_C1 * x);
     if (deg > 1) {
       const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-      PUT(4, RG_C2_0 * xy); PUT(5, RG_C2_1 * yz); PUT(6, RG_C2_2 * (2.f * zz - xx - yy));
-      PUT(7, RG_C2_3 * xz); PUT(8, RG_C2_4 * (xx - yy));
       dx = add(dx, add(add(add(mul(RG_C2_0 * y, SH(4)), mul(RG_C2_2 * 2.f * -x, SH(6))), mul(RG_C2_3 * z, SH(7))), mul(RG_C2_4 * 2.f * x, SH(8))));
       dy = add(dy, add(add(add(mul(RG_C2_0 * x, SH(4)), mul(RG_C2_1 * z, SH(5))), mul(RG_C2_2 * 2.f * -y, SH(6))), mul(RG_C2_4 * 2.f * -y, SH(8))));
       dz = add(dz, add(add(mul(RG_C2_1 * y, SH(5)), mul(RG_C2_2 * 2.f * 2.f * z, SH(6))), mul(RG_C2_3 * x, SH(7))));
+      PUT(4, RG_C2_0 * xy); PUT(5, RG_C2_1 * yz); PUT(6, RG_C2_2 * (2.f * zz - xx - yy));
+      PUT(7, RG_C2_3 * xz); PUT(8, RG_C2_4 * (xx - yy));
       if (deg > 2) {
-        PUT(9, RG_C3_0 * y * (3.f * xx - yy)); PUT(10, RG_C3_1 * xy * z); PUT(11, RG_C3_2 * y * (4.f * zz - xx - yy));
-        PUT(12, RG_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy)); PUT(13, RG_C3_4 * x * (4.f * zz - xx - yy));
-        PUT(14, RG_C3_5 * z * (xx - yy)); PUT(15, RG_C3_6 * x * (xx - 3.f * yy));
         // scalar*vec3 first, further scalars then multiply the vec3 left to right (backward.cu:100-123)
         dx = add(dx, add(add(add(add(add(add(mul(mul(mul(mul(RG_C3_0, SH(9)), 3.f), 2.f), xy), mul(mul(RG_C3_1, SH(10)), yz)),
                                          mul(mul(mul(RG_C3_2, SH(11)), -2.f), xy)),
@@ -95,6 +95,9 @@ RG_HD v3 sh_bwd(int deg, const float* sh, v3 pos, const float campos[3], unsigne
                                  mul(mul(mul(RG_C3_3, SH(12)), 3.f), (2.f * zz - xx - yy))),
                              mul(mul(mul(mul(RG_C3_4, SH(13)), 4.f), 2.f), xz)),
                          mul(mul(RG_C3_5, SH(14)), (xx - yy))));
+        PUT(9, RG_C3_0 * y * (3.f * xx - yy)); PUT(10, RG_C3_1 * xy * z); PUT(11, RG_C3_2 * y * (4.f * zz - xx - yy));
+        PUT(12, RG_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy)); PUT(13, RG_C3_4 * x * (4.f * zz - xx - yy));
+        PUT(14, RG_C3_5 * z * (xx - yy)); PUT(15, RG_C3_6 * x * (xx - 3.f * yy));
       }
     }
   }
@@ -196,7 +199,7 @@ RG_HD void preprocess_bwd(v3 mean, const float* scale3, const float* quat4, cons
       v3 nJi_dp = mul(transpose(nJ_inv), mk3(dplx / clamp_vb, dply / clamp_vb, 0.0f));
       m3 dVinv = outer(W_uvh, add(mul(W_uvh, dL_dvb), mul(W, nJi_dp)));
       v3 dvv = mul(add(dVinv, transpose(dVinv)), g.evmin);
-      const float emin = g.eig.d[g.min_id == 0 ? 0 : (g.min_id == 1 ? 1 : 2)];
+      const float emin = g.min_id == 0 ? g.eig.d[0] : (g.min_id == 1 ? g.eig.d[1] : g.eig.d[2]);
 #pragma unroll
       for (int j = 0; j < 3; j++) {
         if (j != g.min_id) {
