@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--config", default="C2", help="BASELINE.json config (C1..C5); the headline metric is quoted on C2")
     ap.add_argument("--points", type=int, default=0, help="override the number of Gaussians (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-allreduce", action="store_true", help="run the RCCL gradient all-reduce even at world size 1 (path check)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -72,14 +73,16 @@ def main():
         raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU path")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # under torch.distributed.run (any N)
+    if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
     import diff_gaussian_rasterization._C as C
     from synth_scene import CONFIGS, make_config, to_device, upstream_grads
-    from view_parallel import allreduce_gradients
+    from view_parallel import GradBucket
 
+    force_allreduce = args.force_allreduce and launched
     over = {}
     if args.points:
         over["P"] = args.points
@@ -95,6 +98,10 @@ def main():
     g = {k: v.to(dev) for k, v in upstream_grads(scene_cpu, cfg["seed"]).items()}
     P, W, H = s.means3D.shape[0], s.W, s.H
     e = torch.Tensor([])
+    bucket = None
+    if world > 1 or force_allreduce:
+        bucket = GradBucket(P, s.shs.shape[1], dev)   # backward writes its gradients straight into the bucket
+        C.GRAD_ALLOCATOR = bucket.allocator
 
     def step():
         fw = C.rasterize_gaussians(s.bg, s.means3D, e, s.opacities, s.scales, s.rotations, 1.0, e, s.viewmatrix, s.projmatrix, s.tanfovx,
@@ -106,12 +113,12 @@ def main():
                                             g["mdepth"], g["alpha"], g["normal"], normal, s.shs, s.sh_degree, s.campos, geom, R,
                                             binning, img, alpha, s.require_coord, s.require_depth, False)
         grads = dict(dL_dmeans3D=bw[3], dL_dsh=bw[5], dL_dopacity=bw[2], dL_dscales=bw[6], dL_drotations=bw[7])
-        if world > 1:
-            grads = allreduce_gradients(grads, average=True)
+        if bucket is not None:  # the one exchange step of the path: RCCL all-reduce of the gradient bucket
+            grads = bucket.allreduce(average=True)
         return R, radii, grads
 
     def fence():
-        if world > 1:
+        if launched:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -167,7 +174,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_cpu, cfg["seed"])
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if launched:
         dist.barrier()
         dist.destroy_process_group()
 

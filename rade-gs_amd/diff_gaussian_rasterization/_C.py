@@ -68,6 +68,10 @@ _lib = None
 # test hook: when True, the per-Gaussian accumulation scratch of the last backward is kept in LAST_ACC
 KEEP_ACC = False
 LAST_ACC = None
+# Optional allocator for the 8 gradient tensors of the backward: callable(name, shape, dtype, device) -> tensor
+# or None.  A data-parallel caller points it at slices of ONE flat bucket so that the gradient all-reduce needs no
+# gather copy (rade-gs_amd/view_parallel.GradBucket).  Default: plain torch.empty.
+GRAD_ALLOCATOR = None
 
 
 def library():
@@ -213,11 +217,19 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
     M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
     fo = dict(dtype=torch.float32, device=dev)
-    mk = torch.empty if P != 0 else torch.zeros
-    dL_dmeans3D, dL_dmeans2D, dL_dcolors = mk((P, 3), **fo), mk((P, 3), **fo), mk((P, 3), **fo)
-    dL_dopacity, dL_dcov3D = mk((P, 1), **fo), mk((P, 6), **fo)
-    dL_dsh = mk((P, M, 3), **fo)
-    dL_dscales, dL_drotations = mk((P, 3), **fo), mk((P, 4), **fo)
+
+    def mk(name, shape):
+        if P != 0 and GRAD_ALLOCATOR is not None:
+            t = GRAD_ALLOCATOR(name, shape, torch.float32, dev)
+            if t is not None:
+                assert t.shape == torch.Size(shape) and t.is_contiguous() and t.dtype == torch.float32 and t.device == dev
+                return t
+        return torch.empty(shape, **fo) if P != 0 else torch.zeros(shape, **fo)
+
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors = mk("dL_dmeans3D", (P, 3)), mk("dL_dmeans2D", (P, 3)), mk("dL_dcolors", (P, 3))
+    dL_dopacity, dL_dcov3D = mk("dL_dopacity", (P, 1)), mk("dL_dcov3D", (P, 6))
+    dL_dsh = mk("dL_dsh", (P, M, 3))
+    dL_dscales, dL_drotations = mk("dL_dscales", (P, 3)), mk("dL_drotations", (P, 4))
     if P != 0:
         bg, m3, col = _f32(background, "bg"), _f32(means3D, "means3D"), _f32(colors, "colors_precomp")
         sc, rot, cov = _f32(scales, "scales"), _f32(rotations, "rotations"), _f32(cov3D_precomp, "cov3D_precomp")

