@@ -23,6 +23,7 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
          "-Wno-unused-value", "-I", CSRC]
 UNITS = {
     "radegs_prims": ["radegs_prims.hip", "rg_prims.h"],
+    "radegs_sort": ["radegs_sort.hip", "rg_prims.h"],
     "radegs_kernels": ["radegs_kernels.hip", "rg_launch.inc", "rg_math.h", "rg_blend.h", "rg_preprocess.h", "rg_preprocess_bwd.h",
                        "rg_layout.h", "rg_prims.h", os.path.join("..", "..", "include", "radegs.h")],
 }

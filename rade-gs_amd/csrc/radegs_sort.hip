@@ -1,0 +1,319 @@
+// radegs_sort.hip -- hand-written stable LSD radix sort of (u32 key, u32 value) pairs for the binning stage.
+//
+// Replaces the two device-library sorts of round 1 (the counterpart of cub::DeviceRadixSort::SortPairs at
+// DGR/cuda_rasterizer/rasterizer_impl.cu:376-381).  Both sorts on this path are small by HBM standards (1M
+// depth keys; ~4M (tile, gaussian) instances with a 13-bit key), so the design goal is few, short kernels:
+//
+//   per 8-bit pass:   digit_histogram_kernel   one 256-bin histogram per 2048-item block   (reads keys)
+//                     scan_rows_kernel         one workgroup per digit scans its row of block counts
+//                     scatter_kernel           stable scatter                                (reads keys+values, writes both)
+//
+// Stability (what makes ties keep ascending Gaussian index) comes from the scatter's ranking: a wave
+// owns a CONTIGUOUS run of the block's items and walks it 64 items at a time; within one step, lanes with equal
+// digits find each other with 8 ballots (one per digit bit) and rank themselves by popcount of the lower lanes;
+// across steps a per-wave LDS counter array carries the running count per digit; across waves the block first
+// histograms every wave's run (LDS atomics) and prefix-sums those per digit.  No atomics on global memory, no
+// inter-workgroup communication, deterministic output.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rg_prims.h"
+
+namespace rg {
+
+namespace {
+
+constexpr int kSortThreads = 256;                 // 4 waves
+constexpr int kBins = 256;
+
+template <int ITEMS>
+__global__ void __launch_bounds__(kSortThreads) digit_histogram_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
+                                                                       uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblocks) {
+  __shared__ uint32_t h[kBins];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * (uint32_t)(kSortThreads * ITEMS);
+#pragma unroll 4
+  for (int r = 0; r < ITEMS; r++) {
+    const uint32_t i = base + r * kSortThreads + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];  // [digit][block]
+}
+
+// One workgroup per digit: exclusive scan of that digit's per-block counts (in place) + the digit's total.
+__global__ void __launch_bounds__(kSortThreads) scan_rows_kernel(uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t* __restrict__ totals) {
+  __shared__ uint32_t wave_sum[4];
+  __shared__ uint32_t carry_s;
+  uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t start = 0; start < nblocks; start += kSortThreads) {
+    const uint32_t i = start + threadIdx.x;
+    const uint32_t v = i < nblocks ? row[i] : 0u;
+    uint32_t x = v;  // inclusive scan inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) wave_sum[wave] = x;
+    __syncthreads();
+    uint32_t off = carry_s;
+    for (int w = 0; w < wave; w++) off += wave_sum[w];
+    if (i < nblocks) row[i] = off + x - v;
+    __syncthreads();
+    if (threadIdx.x == kSortThreads - 1) carry_s = off + x;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+}
+
+// exclusive scan of one value per thread across the 256-thread block
+__device__ __forceinline__ uint32_t block256_exclusive(uint32_t t, uint32_t* tmp4) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t x = t;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = __shfl_up(x, d);
+    if (lane >= d) x += y;
+  }
+  __syncthreads();
+  if (lane == 63) tmp4[wave] = x;
+  __syncthreads();
+  uint32_t off = 0;
+  for (int w = 0; w < wave; w++) off += tmp4[w];
+  return off + x - t;
+}
+
+template <int ITEMS>
+__global__ void __launch_bounds__(kSortThreads) scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                               uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
+                                                               int shift, uint32_t mask, int nbits, const uint32_t* __restrict__ hist,
+                                                               uint32_t nblocks, const uint32_t* __restrict__ totals) {
+  constexpr int BLOCK_ITEMS = kSortThreads * ITEMS, WAVE_ITEMS = 64 * ITEMS;
+  __shared__ uint32_t digit_base[kBins];      // global offset of this block's first item of each digit
+  __shared__ uint32_t local_start[kBins];     // position of each digit's first item in the block-local sorted order
+  __shared__ uint32_t wave_cnt[4][kBins];     // histogram of each wave's run, then running rank counters
+  __shared__ uint32_t scan_tmp[4];
+  __shared__ uint32_t lds_k[BLOCK_ITEMS];     // the block's items reordered by digit (stable), so that the global
+  __shared__ uint32_t lds_v[BLOCK_ITEMS];     // writes below go out in contiguous per-digit runs
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  digit_base[tid] = block256_exclusive(totals[tid], scan_tmp) + hist[(size_t)tid * nblocks + blockIdx.x];
+#pragma unroll
+  for (int w = 0; w < 4; w++) wave_cnt[w][tid] = 0;
+  __syncthreads();
+  const uint32_t block0 = blockIdx.x * (uint32_t)BLOCK_ITEMS;
+  const uint32_t run0 = block0 + wave * (uint32_t)WAVE_ITEMS;  // this wave's contiguous run
+  // ---- phase A: histogram of every wave's run ----
+#pragma unroll 4
+  for (int r = 0; r < ITEMS; r++) {
+    const uint32_t i = run0 + r * 64 + lane;
+    if (i < n) atomicAdd(&wave_cnt[wave][(keys_in[i] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  // per digit: the 4 wave counts become exclusive prefixes (wave w starts after waves < w); block total per digit
+  uint32_t block_count = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const uint32_t c = wave_cnt[w][tid];
+    wave_cnt[w][tid] = block_count;
+    block_count += c;
+  }
+  local_start[tid] = block256_exclusive(block_count, scan_tmp);
+  __syncthreads();
+  // ---- phase B: stable ranks, 64 consecutive items per step; items land in LDS in digit order ----
+  for (int r = 0; r < ITEMS; r++) {
+    const uint32_t i = run0 + r * 64 + lane;
+    const bool valid = i < n;
+    const uint32_t key = valid ? keys_in[i] : 0xFFFFFFFFu;
+    const uint32_t val = valid ? (vals_in ? vals_in[i] : i) : 0u;
+    const uint32_t digit = (key >> shift) & mask;
+    // lanes holding the same digit (invalid lanes only match each other and are never counted)
+    uint64_t peers = __ballot(valid);
+    if (!valid) peers = ~peers;
+    for (int b = 0; b < nbits; b++) {
+      const bool bit = (digit >> b) & 1u;
+      const uint64_t m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    const uint64_t lower = peers & ((1ull << lane) - 1ull);
+    const uint32_t rank_in_step = (uint32_t)__popcll(lower);
+    const uint32_t count_in_step = (uint32_t)__popcll(peers);
+    uint32_t before = 0;
+    if (valid) before = wave_cnt[wave][digit];          // items of this digit earlier in the block order
+    // the first lane of every peer group advances the running counter (one writer per digit: no atomic needed)
+    __builtin_amdgcn_wave_barrier();
+    if (valid && lower == 0) wave_cnt[wave][digit] = before + count_in_step;
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+      const uint32_t pos = local_start[digit] + before + rank_in_step;
+      lds_k[pos] = key;
+      lds_v[pos] = val;
+    }
+  }
+  __syncthreads();
+  // ---- write out: consecutive local positions of one digit are consecutive global addresses ----
+  const uint32_t count = min((uint32_t)BLOCK_ITEMS, n - block0);
+  for (uint32_t pos = tid; pos < count; pos += kSortThreads) {
+    const uint32_t key = lds_k[pos];
+    const uint32_t digit = (key >> shift) & mask;
+    const uint32_t dst = digit_base[digit] + (pos - local_start[digit]);
+    keys_out[dst] = key;
+    vals_out[dst] = lds_v[pos];
+  }
+}
+
+// ---- inclusive scan of tiles_touched gathered through idx_sorted (reduce, scan the block sums, scan) ----
+constexpr int kScanItems = 16;  // per thread -> 4096 per block
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
+  __shared__ uint32_t ws[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = __shfl_up(x, d);
+    if (lane >= d) x += y;
+  }
+  __syncthreads();  // protects ws across successive calls
+  if (lane == 63) ws[wave] = x;
+  __syncthreads();
+  uint32_t off = 0;
+  for (int w = 0; w < wave; w++) off += ws[w];
+  if (total) *total = ws[0] + ws[1] + ws[2] + ws[3];
+  return off + x - v;
+}
+
+__global__ void __launch_bounds__(kSortThreads) gather_block_sums_kernel(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ idx,
+                                                                         uint32_t n, uint32_t* __restrict__ block_sums,
+                                                                         uint32_t* __restrict__ gathered) {
+  const uint32_t base = blockIdx.x * (uint32_t)(kSortThreads * kScanItems) + threadIdx.x * kScanItems;
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    const uint32_t i = base + k;
+    if (i < n) {
+      const uint32_t v = vals[idx[i]];  // the only random gather; the scan pass re-reads it sequentially
+      gathered[i] = v;
+      s += v;
+    }
+  }
+  uint32_t total;
+  block_exclusive_scan(s, &total);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kSortThreads) scan_block_sums_kernel(uint32_t* __restrict__ block_sums, uint32_t nblocks) {
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t start = 0; start < nblocks; start += kSortThreads) {
+    const uint32_t i = start + threadIdx.x;
+    const uint32_t v = i < nblocks ? block_sums[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan(v, &total);
+    const uint32_t c = carry;
+    if (i < nblocks) block_sums[i] = c + ex;  // exclusive prefix of the block sums
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + total;
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(kSortThreads) gather_scan_kernel(const uint32_t* __restrict__ gathered, uint32_t n,
+                                                                   const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ out) {
+  const uint32_t base = blockIdx.x * (uint32_t)(kSortThreads * kScanItems) + threadIdx.x * kScanItems;
+  uint32_t v[kScanItems];
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    const uint32_t i = base + k;
+    v[k] = i < n ? gathered[i] : 0u;
+    s += v[k];
+  }
+  uint32_t run = block_sums[blockIdx.x] + block_exclusive_scan(s, nullptr);
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    const uint32_t i = base + k;
+    run += v[k];
+    if (i < n) out[i] = run;  // inclusive
+  }
+}
+
+}  // namespace
+
+static int sort_items_per_thread(size_t n) { return n > (size_t(3) << 20) ? 16 : 8; }
+
+size_t sort_temp_bytes(size_t n) {
+  const size_t nblocks = (n + kSortThreads * 8 - 1) / (kSortThreads * 8);  // upper bound over both block sizes
+  // ping-pong keys + values, [256][nblocks] histogram, 256 totals
+  return 2 * (n * sizeof(uint32_t) + 256) + (kBins * (nblocks + 1)) * sizeof(uint32_t) + kBins * sizeof(uint32_t) + 1024;
+}
+
+// Sorts (keys_in, vals_in) by bits [0, end_bit) of the key into (keys_out, vals_out).  vals_in == nullptr means
+// "values are 0..n-1".  keys_in/vals_in are left untouched; temp must hold sort_temp_bytes(n).
+hipError_t radix_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
+                                uint32_t* vals_out, size_t n, int end_bit, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  if (temp_bytes < sort_temp_bytes(n)) return hipErrorInvalidValue;
+  if (n > 0xFFFFFFFFull - 65536) return hipErrorInvalidValue;
+  const int items = sort_items_per_thread(n);
+  const uint32_t nblocks = (uint32_t)((n + (size_t)kSortThreads * items - 1) / ((size_t)kSortThreads * items));
+  char* p = static_cast<char*>(temp);
+  auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~size_t(255); return r; };
+  uint32_t* tkeys = reinterpret_cast<uint32_t*>(take(n * sizeof(uint32_t)));
+  uint32_t* tvals = reinterpret_cast<uint32_t*>(take(n * sizeof(uint32_t)));
+  uint32_t* hist = reinterpret_cast<uint32_t*>(take((size_t)kBins * nblocks * sizeof(uint32_t)));
+  uint32_t* totals = reinterpret_cast<uint32_t*>(take(kBins * sizeof(uint32_t)));
+  const int passes = (end_bit + 7) / 8;
+  const int width = (end_bit + passes - 1) / passes;  // balanced digits: 13 bits -> 7 + 6, 32 -> 8 x 4
+  const uint32_t* src_k = keys_in;
+  const uint32_t* src_v = vals_in;
+  for (int pass = 0; pass < passes; pass++) {
+    const int shift = pass * width;
+    const int nbits = (end_bit - shift) < width ? (end_bit - shift) : width;
+    const uint32_t mask = (1u << nbits) - 1u;
+    // destinations alternate so that the LAST pass lands in (keys_out, vals_out)
+    const bool to_out = ((passes - 1 - pass) % 2) == 0;
+    uint32_t* dst_k = to_out ? keys_out : tkeys;
+    uint32_t* dst_v = to_out ? vals_out : tvals;
+    if (items == 16) {
+      hipLaunchKernelGGL(digit_histogram_kernel<16>, dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, (uint32_t)n, shift, mask, hist, nblocks);
+      hipLaunchKernelGGL(scan_rows_kernel, dim3(kBins), dim3(kSortThreads), 0, stream, hist, nblocks, totals);
+      hipLaunchKernelGGL(scatter_kernel<16>, dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, src_v, dst_k, dst_v, (uint32_t)n, shift,
+                         mask, nbits, hist, nblocks, totals);
+    } else {
+      hipLaunchKernelGGL(digit_histogram_kernel<8>, dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, (uint32_t)n, shift, mask, hist, nblocks);
+      hipLaunchKernelGGL(scan_rows_kernel, dim3(kBins), dim3(kSortThreads), 0, stream, hist, nblocks, totals);
+      hipLaunchKernelGGL(scatter_kernel<8>, dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, src_v, dst_k, dst_v, (uint32_t)n, shift,
+                         mask, nbits, hist, nblocks, totals);
+    }
+    src_k = dst_k;
+    src_v = dst_v;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace rg
+
+namespace rg {
+size_t scan_temp_bytes(size_t n) {
+  return ((n + kSortThreads * kScanItems - 1) / (kSortThreads * kScanItems) + 1) * sizeof(uint32_t) + 512 + n * sizeof(uint32_t);
+}
+
+// out[i] = sum_{j <= i} vals[idx[j]]   (rasterizer_impl.cu:350's InclusiveSum, taken in depth order)
+hipError_t inclusive_scan_gather_u32(void* temp, size_t temp_bytes, const uint32_t* vals, const uint32_t* idx, uint32_t* out, size_t n,
+                                     hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  if (temp_bytes < scan_temp_bytes(n)) return hipErrorInvalidValue;
+  const uint32_t nblocks = (uint32_t)((n + kSortThreads * kScanItems - 1) / (kSortThreads * kScanItems));
+  uint32_t* block_sums = static_cast<uint32_t*>(temp);
+  uint32_t* gathered = block_sums + ((nblocks + 64) & ~63u);
+  hipLaunchKernelGGL(gather_block_sums_kernel, dim3(nblocks), dim3(kSortThreads), 0, stream, vals, idx, (uint32_t)n, block_sums, gathered);
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(kSortThreads), 0, stream, block_sums, nblocks);
+  hipLaunchKernelGGL(gather_scan_kernel, dim3(nblocks), dim3(kSortThreads), 0, stream, gathered, (uint32_t)n, block_sums, out);
+  return hipGetLastError();
+}
+}  // namespace rg

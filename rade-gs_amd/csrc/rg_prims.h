@@ -22,4 +22,12 @@ hipError_t scan_tiles_in_depth_order(void* temp, size_t temp_bytes, const uint32
 hipError_t sort_by_tile(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
                         uint32_t* vals_out, size_t R, int tile_bits, hipStream_t stream);
 
+// ---- hand-written replacements (radegs_sort.hip); the rocPRIM versions above stay as an on-device cross-check ----
+size_t sort_temp_bytes(size_t n);
+size_t scan_temp_bytes(size_t n);
+hipError_t radix_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
+                                uint32_t* vals_out, size_t n, int end_bit, hipStream_t stream);
+hipError_t inclusive_scan_gather_u32(void* temp, size_t temp_bytes, const uint32_t* vals, const uint32_t* idx, uint32_t* out, size_t n,
+                                     hipStream_t stream);
+
 }  // namespace rg

@@ -223,3 +223,29 @@ def test_debug_flag_and_stream():
         got = HipRun(s, _dev(), debug=True).forward_native()
     st.synchronize()
     assert torch.equal(ref[1], got[1]) and ref[0] == got[0]
+
+
+def test_handwritten_sort_matches_device_library():
+    """The hand-written radix sort / scan (csrc/radegs_sort.hip) against rocPRIM's (RADEGS_PRIMS=rocprim, read once
+    per process, hence the subprocess): identical point_list and ranges on a scene big enough for several blocks."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib, numpy as np, torch\n"
+        "sys.path[:0] = [%r, %r, %r]\n"
+        "from gpu_util import HipRun\n"
+        "from synth_scene import make_scene\n"
+        "s = make_scene(150000, 640, 360, sh_degree=1, mu_px=2.5, seed=77, require_depth=True)\n"
+        "h = HipRun(s, 'cuda:0'); st = h.forward_native(); torch.cuda.synchronize()\n"
+        "pl = h.export('point_list', torch.int32, st[0]); rg = h.export('ranges', torch.int32, 2 * 40 * 23)\n"
+        "print('HASH', st[0], hashlib.sha1(pl.tobytes() + rg.tobytes()).hexdigest())\n"
+    ) % tuple(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), p) for p in ("", "rade-gs_amd", "tests"))
+    outs = []
+    for prims in ("", "rocprim"):
+        env = dict(os.environ, RADEGS_PRIMS=prims)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][0])
+    assert outs[0] == outs[1], outs
