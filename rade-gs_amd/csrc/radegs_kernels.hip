@@ -680,7 +680,7 @@ __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementw
 __device__ __forceinline__ f2 bc2(float v) { return f2{v, v}; }
 
 template <bool COORD, bool DEPTH, int PPL>
-__global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 2 : 4))) blend_bwd_packed_kernel(const BlendBwdArgs a) {
+__global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 2 : 5))) blend_bwd_packed_kernel(const BlendBwdArgs a) {
   static_assert(PPL == 2 || PPL == 4, "pairs of pixels per lane");
   constexpr bool NORMAL = COORD || DEPTH;
   constexpr int NP = PPL / 2;  // pairs per lane
