@@ -106,25 +106,48 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* m
 }
 
 // ============================================================================== binning ==
-// One thread per Gaussian IN DEPTH ORDER; writes (tile id, gaussian idx) for every tile of its
-// rect, rows outer / columns inner -- the emission order of rasterizer_impl.cu:98-109.
+// One thread per Gaussian IN DEPTH ORDER; writes (tile id, gaussian idx) for every tile of its rect, rows outer /
+// columns inner -- the emission order of rasterizer_impl.cu:98-109.  Splats with few tiles are written by their own
+// lane; a splat with many tiles (heavy-overdraw scenes: hundreds per splat) is handed to the whole wave, which writes
+// its instances 64 at a time to consecutive addresses -- coalesced, and no lane serialises a 300-iteration loop.
+constexpr int kEmitCoopThreshold = 16;
 __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32_t* idx_sorted, const uint32_t* offsets,
                                                             const uint32_t* tiles_touched, const float4* splat_a, const int* radii,
                                                             int gx, int gy, uint32_t* tile_keys, uint32_t* vals) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= P) return;
-  const uint32_t idx = idx_sorted[i];
-  if (tiles_touched[idx] == 0) return;
-  uint32_t off = (i == 0) ? 0u : offsets[i - 1];
-  const float4 a0 = splat_a[4 * (size_t)idx];
-  int x0, y0, x1, y1;
-  tile_rect(a0.x, a0.y, radii[idx], gx, gy, x0, y0, x1, y1);
-  for (int y = y0; y < y1; y++)
-    for (int x = x0; x < x1; x++) {
-      tile_keys[off] = (uint32_t)(y * gx + x);
-      vals[off] = idx;
-      off++;
+  const int lane = threadIdx.x & 63;
+  uint32_t idx = 0, ntiles = 0, off = 0;
+  int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  if (i < P) {
+    idx = idx_sorted[i];
+    ntiles = tiles_touched[idx];
+    if (ntiles) {
+      off = (i == 0) ? 0u : offsets[i - 1];
+      const float4 a0 = splat_a[4 * (size_t)idx];
+      tile_rect(a0.x, a0.y, radii[idx], gx, gy, x0, y0, x1, y1);
     }
+  }
+  const bool big = ntiles > (uint32_t)kEmitCoopThreshold;
+  if (ntiles && !big) {
+    for (int y = y0; y < y1; y++)
+      for (int x = x0; x < x1; x++) {
+        tile_keys[off] = (uint32_t)(y * gx + x);
+        vals[off] = idx;
+        off++;
+      }
+  }
+  uint64_t todo = __ballot(big);
+  while (todo) {
+    const int src = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    const uint32_t g_idx = __shfl(idx, src), g_n = __shfl(ntiles, src), g_off = __shfl(off, src);
+    const int g_x0 = __shfl(x0, src), g_y0 = __shfl(y0, src), g_w = __shfl(x1, src) - g_x0;
+    for (uint32_t t = lane; t < g_n; t += 64) {
+      const int ty = (int)(t / (uint32_t)g_w), tx = (int)(t - (uint32_t)ty * (uint32_t)g_w);
+      tile_keys[g_off + t] = (uint32_t)((g_y0 + ty) * gx + (g_x0 + tx));
+      vals[g_off + t] = g_idx;
+    }
+  }
 }
 
 __global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint32_t* keys, uint2* ranges) {
