@@ -161,7 +161,7 @@ def main():
                                    f"RGB{'+coord' if c else ''}{'+depth' if d else ''}{'+normal' if (c or d) else ''}",
                        "parallelism": f"view-parallel x{world}" + (", RCCL all-reduce of 236 B/Gaussian grads" if world > 1 else ""),
                        "num_rendered": int(R), "visible": Pv},
-            "roofline": {"bound": "hbm", "kernel": dom + "_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": {"blend_bwd": "blend_bwd_packed_kernel"}.get(dom, dom + "_kernel"), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": int(ab[dom]), "avg_launch_ms": round(dom_ms, 4)},
             "path_roofline": {"algorithmic_bytes_per_view": int(ab["total"]), "gpu_ms_per_view": round(gpu_ms, 4),
