@@ -11,6 +11,8 @@
  *                            (called from RasterizeGaussiansBackwardCUDA, DGR/rasterize_points.cu:136-246)
  *   radegs_mark_visible  <-  CudaRasterizer::Rasterizer::markVisible DGR/cuda_rasterizer/rasterizer.h:24-29
  *                            (called from markVisible,               DGR/rasterize_points.cu:248-267)
+ *   radegs_integrate     <-  CudaRasterizer::Rasterizer::integrate  DGR/cuda_rasterizer/rasterizer.h:112-147
+ *                            (called from IntegrateGaussiansToPointsCUDA, DGR/rasterize_points.cu:269-388)
  *
  * Conventions kept from the reference:
  *   - plain device pointers + sizes; NULL means "tensor not provided" (the reference tests
@@ -127,6 +129,44 @@ int radegs_backward(const RadegsBwdArgs* args, radegs_alloc_fn accum_alloc, void
 /* present[i] = 1 iff Gaussian i passes the near-plane test (view z > 0.2). */
 int radegs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, unsigned char* present,
                         void* stream);
+
+typedef struct RadegsIntegrateArgs {
+  int P, D, M;                  /* Gaussians, as in RadegsFwdArgs */
+  int PN;                       /* number of query points */
+  int width, height;
+  const float* background;      /* [3] */
+  const float* means3D;         /* [P,3] */
+  const float* shs;             /* [P,M,3] or NULL */
+  const float* colors_precomp;  /* [P,3] or NULL */
+  const float* opacities;       /* [P] */
+  const float* scales;          /* [P,3] or NULL */
+  const float* rotations;       /* [P,4] or NULL */
+  const float* cov3D_precomp;   /* [P,6] or NULL */
+  const float* viewmatrix;      /* [16] transposed */
+  const float* projmatrix;      /* [16] transposed */
+  const float* cam_pos;         /* [3] */
+  const float* points3D;        /* [PN,3] query points (world space) */
+  float scale_modifier, tan_fovx, tan_fovy, kernel_size;
+  int debug;
+  /* outputs; every element is written by the call (initial values of rasterize_points.cu:312-320 included) */
+  float* out_color;             /* [9,H,W]: rgb, expected depth, median depth, 0, max depth, alpha, #points in the pixel */
+  float* out_alpha_integrated;  /* [PN]   1 for points that do not project into the image */
+  float* out_color_integrated;  /* [PN,3] colour of the pixel the point falls in */
+  float* out_coordinate2d;      /* [PN,2] projected position in pixels */
+  float* out_sdf;               /* [PN]   median-surface depth along the ray minus point depth; -1000 if not projected */
+  int* radii;                   /* [P] */
+} RadegsIntegrateArgs;
+
+/* Integrates the Gaussians' opacity along the ray of every query point (GOF-style; used by mesh extraction).
+ * `point_alloc` provides the point/INTE state (the reference's point + point-binning buffers).  Returns num_rendered.
+ * Documented deviations from the reference's undefined behaviour: (1) for ill-conditioned Gaussians (smallest
+ * covariance eigenvalue <= 1e-8) the inverse ray-space covariance is ZERO: upstream's shadowed variable
+ * (forward.cu:223) stores an uninitialised matrix there; (2) contributor ids are 32-bit (upstream truncates to uint16, wrong only for tile lists longer than
+ * 65535 entries); (3) the exponent of the point opacity is clamped at +80 (a non-PSD ill-conditioned matrix would
+ * otherwise overflow expf). */
+int radegs_integrate(const RadegsIntegrateArgs* args, radegs_alloc_fn geom_alloc, void* geom_user, radegs_alloc_fn binning_alloc,
+                     void* binning_user, radegs_alloc_fn image_alloc, void* image_user, radegs_alloc_fn point_alloc, void* point_user,
+                     void* stream);
 
 /* Sizes of the geometry / image state for (P) and (W*H) -- the binning size depends on R and is
  * requested through the callback. */

@@ -39,6 +39,8 @@ def lib():
         L.oracle_backward.argtypes = [ctypes.c_void_p] * 8
         L.oracle_get.restype = ctypes.c_longlong
         L.oracle_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_longlong]
+        L.oracle_integrate.restype = ctypes.c_int
+        L.oracle_integrate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.oracle_stat_pairs.restype = ctypes.c_longlong
         L.oracle_stat_pairs.argtypes = [ctypes.c_void_p]
         L.oracle_stat_blended.restype = ctypes.c_longlong
@@ -71,7 +73,7 @@ def _ptr(a):
     return None if a is None or a.size == 0 else a.ctypes.data_as(ctypes.c_void_p)
 
 
-_INT_ARRAYS = {"clamped": np.uint8, "radii": np.int32, "tiles_touched": np.uint32, "point_offsets": np.uint32,
+_INT_ARRAYS = {"condition": np.uint8, "point_ranges": np.uint32, "pt_list": np.uint32, "clamped": np.uint8, "radii": np.int32, "tiles_touched": np.uint32, "point_offsets": np.uint32,
                "keys_sorted": np.uint64, "point_list": np.uint32, "ranges": np.uint32, "n_contrib": np.uint32}
 
 
@@ -121,6 +123,16 @@ class Oracle:
         if n:
             lib().oracle_get(self._h, name.encode(), out.ctypes.data_as(ctypes.c_void_p), n)
         return out.reshape(shape) if shape is not None else out
+
+    def integrate(self, points3D):
+        """GaussianRasterizer.integrate (DGR/diff_gaussian_rasterization/__init__.py:239-306): returns
+        (color[9,H,W], alpha_integrated[PN], color_integrated[PN,3], point_coordinate[PN,2], point_sdf[PN], radii)."""
+        pts = _np(points3D, self.dt)
+        PN = pts.shape[0]
+        self.num_rendered = lib().oracle_integrate(self._h, PN, _ptr(pts))
+        H, W = self.H, self.W
+        return (self.get("out9", (9, H, W)), self.get("out_alpha_integrated"), self.get("out_color_integrated", (PN, 3)),
+                self.get("out_coordinate2d", (PN, 2)), self.get("out_sdf"), self.get("radii"))
 
     def outputs(self):
         """The 8-tuple of DGR/diff_gaussian_rasterization/__init__.py:101 as numpy arrays."""

@@ -224,6 +224,13 @@ template <class R> struct Oracle {
       dL_dnormals, dL_dconic, dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations;
   // render-bwd per-Gaussian accumulators before the per-Gaussian chain rule (kept for tests)
   std::vector<R> acc_dmeans2D, acc_dconic, acc_dopacity, acc_dcolors;
+  // ---- integrate() path (GOF point integration) ----
+  bool inte = false;                     // preprocess with the INTE template switch (forward.cu:187-235)
+  int PN = 0;
+  std::vector<R> invraycov, points3D, points2D, point_depths;
+  std::vector<uint8_t> condition;
+  std::vector<uint32_t> point_tiles, pt_list, point_ranges;
+  std::vector<R> out9, final_T, out_alpha_integrated, out_color_integrated, out_coordinate2d, out_sdf;
   int64_t stat_pairs_fwd = 0;    // (pixel, list entry) pairs visited by the forward blend
   int64_t stat_blended_fwd = 0;  // pairs that passed every threshold and were blended
 
@@ -340,7 +347,28 @@ template <class R> struct Oracle {
       V3<R> cam_n = nJ * ray_n;
       V3<R> nrm = normalize(cam_n);
       normals[3 * idx] = nrm.x; normals[3 * idx + 1] = nrm.y; normals[3 * idx + 2] = nrm.z;
+      if (inte) {  // computeCov2D<true>, forward.cu:187-235: inverse covariance in ray space (u/f, v/f, t)
+        M3<R> icr;
+        if (g.well_conditioned) {
+          R ltz = u2 + v2 + 1;
+          M3<R> full(v2 + 1, -uv, txtz / l * ltz, -uv, u2 + 1, tytz / l * ltz, -txtz, -tytz, 1 / l * ltz);
+          M3<R> nJ_inv_full = (t.z / (u2 + v2 + 1)) * full;
+          M3<R> T2 = g.W * transpose(nJ_inv_full);
+          icr = transpose(T2) * g.Vrk_inv * T2;
+        } else {
+          // Upstream declares a second, shadowing `inv_cov_ray` in this branch (forward.cu:223): what it computes there is
+          // discarded and the outer, UNINITIALISED matrix is scaled and stored (undefined behaviour).  The discarded value is
+          // itself meaningless (eigenvalues of a rank-1 matrix: 1/rounding-noise), so the deterministic reading is taken:
+          // the matrix is zero.  In integrate_pixel such a Gaussian then acts as an opaque step at its depth plane.
+          icr = M3<R>(R(0), R(0), R(0), R(0), R(0), R(0), R(0), R(0), R(0));
+        }
+        M3<R> sc(1 / focal_x, R(0), R(0), R(0), 1 / focal_y, R(0), R(0), R(0), R(1));
+        icr = sc * icr * sc;
+        R* o6 = &invraycov[6 * idx];
+        o6[0] = icr[0][0]; o6[1] = icr[0][1]; o6[2] = icr[0][2]; o6[3] = icr[1][1]; o6[4] = icr[1][2]; o6[5] = icr[2][2];
+      }
     }
+    if (inte) condition[idx] = g.well_conditioned ? 1 : 0;
 
     // ---- back in preprocessCUDA, forward.cu:381-422 ----
     ts[idx] = std::sqrt(p_view.x * p_view.x + p_view.y * p_view.y + p_view.z * p_view.z);
@@ -526,6 +554,220 @@ template <class R> struct Oracle {
     } else {
       // P == 0: every output stays at its zero fill (the reference skips the whole call)
     }
+    register_all();
+    return num_rendered;
+  }
+
+  // ---------------------------------------------------------------- integrate ----
+  // integrateCUDA for one pixel, forward.cu:938-1372.  MAXC = MAX_NUM_CONTRIBUTORS*4, MAXP = MAX_NUM_PROJECTED
+  // (auxiliary.h:27-29).  Gaussian depth for the blend is ts (|p_view|, rasterizer_impl.cu:823), the sort key is z.
+  void integrate_pixel(uint32_t px, uint32_t py) {
+    constexpr int MAXC = 512 * 4, MAXP = 256;
+    const size_t HW = size_t(H) * W;
+    const uint32_t pix_id = W * py + px;
+    const R pixfx = R(px) + R(0.5f), pixfy = R(py) + R(0.5f);
+    const uint32_t tile = (py / TILE) * gx + (px / TILE);
+    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    const uint32_t p0 = point_ranges[2 * tile], p1 = point_ranges[2 * tile + 1];
+    const R* feat = feature_ptr();
+    R T = R(1.0f);
+    uint32_t contributor = 0, last_contributor = 0;
+    R C[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    R mid_depth_center = 0, mid_plane[2] = {0, 0}, mid_mean2d[2] = {0, 0};
+    uint32_t n_local = 0;
+    std::vector<uint16_t> contributed(MAXC, 0);
+    R corner_T[5] = {1, 1, 1, 1, 1};
+    const R offx[5] = {R(0.0f), R(-0.5f), R(0.5f), R(-0.5f), R(0.5f)}, offy[5] = {R(0.0f), R(-0.5f), R(-0.5f), R(0.5f), R(0.5f)};
+    for (uint32_t k = r0; k < r1; k++) {
+      contributor++;
+      const uint32_t g = point_list[k];
+      const R cx = conic_opacity[4 * g], cy = conic_opacity[4 * g + 1], cz = conic_opacity[4 * g + 2], co = conic_opacity[4 * g + 3];
+      const R depth_center = ts[g];
+      const R dpx = ray_planes[2 * g], dpy = ray_planes[2 * g + 1];
+      const R mx = means2D[2 * g], my = means2D[2 * g + 1];
+      bool used = false;
+      for (int c = 0; c < 5; ++c) {
+        const R dx = mx - pixfx - offx[c], dy = my - pixfy - offy[c];
+        const R depth = depth_center + (dpx * dx + dpy * dy);
+        const R power = R(-0.5f) * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+        if (power > R(0.0f)) continue;
+        const R alpha = std::fmin(R(0.99f), co * exp_spec(power));
+        if (alpha < R(1.0f) / R(255.0f)) continue;
+        const R test_T = corner_T[c] * (1 - alpha);
+        if (test_T < R(0.0001f)) continue;
+        if (c == 0) for (int ch = 0; ch < 3; ch++) C[ch] += feat[3 * g + ch] * alpha * T;
+        if (depth > C[6]) C[6] = depth;
+        if (c == 0) {
+          C[7] += alpha * T;
+          C[3] += depth * alpha * T;
+          if (T > R(0.5)) { C[4] = depth; mid_depth_center = depth_center; mid_plane[0] = dpx; mid_plane[1] = dpy; mid_mean2d[0] = mx; mid_mean2d[1] = my; }
+          T = test_T;
+        }
+        corner_T[c] = test_T;
+        used = true;
+      }
+      if (used) {
+        last_contributor = contributor;
+        contributed[n_local] = static_cast<uint16_t>(contributor);
+        n_local += 1;
+        if (n_local >= MAXC) break;  // upstream prints an error and stops this pixel (forward.cu:1121-1125)
+      }
+    }
+    final_T[pix_id] = T;
+    n_contrib[pix_id] = last_contributor;
+    for (int ch = 0; ch < 3; ch++) out9[ch * HW + pix_id] = C[ch] + T * bg[ch];
+    out9[3 * HW + pix_id] = C[3];
+    out9[4 * HW + pix_id] = C[4];
+    out9[6 * HW + pix_id] = C[6];
+    out9[7 * HW + pix_id] = C[7];
+
+    // ---- points that project into this pixel, MAXP at a time ----
+    uint32_t counter_last = 0;
+    int total_projected = 0;
+    while (true) {
+      int num_projected = 0;
+      bool exceed = false;
+      uint32_t counter = 0;
+      int pid[MAXP]; R pxy[MAXP][2], pdepth[MAXP];
+      for (uint32_t k = p0; k < p1; k++) {
+        counter++;
+        if (counter <= counter_last) continue;
+        const uint32_t q = pt_list[k];
+        const R qx = points2D[2 * q], qy = points2D[2 * q + 1];
+        if ((static_cast<double>(qx) >= (static_cast<double>(pixfx) - 0.5)) && (static_cast<double>(qx) < (static_cast<double>(pixfx) + 0.5)) &&
+            (static_cast<double>(qy) >= (static_cast<double>(pixfy) - 0.5)) && (static_cast<double>(qy) < (static_cast<double>(pixfy) + 0.5))) {
+          if (num_projected >= MAXP) { exceed = true; break; }
+          pid[num_projected] = static_cast<int>(q);
+          pxy[num_projected][0] = qx; pxy[num_projected][1] = qy;
+          pdepth[num_projected] = point_depths[q];
+          num_projected += 1;
+        }
+      }
+      counter_last = counter - 1;
+      total_projected += num_projected;
+      R palpha[MAXP], pT[MAXP];
+      for (int i = 0; i < num_projected; i++) { palpha[i] = R(0.f); pT[i] = R(1.f); }
+      uint32_t num_iterated = 0;
+      uint16_t nsecond = 0;
+      for (uint32_t k = r0; k < r1; k++) {
+        num_iterated++;
+        if (num_iterated > last_contributor) break;
+        if (num_iterated != static_cast<uint32_t>(contributed[nsecond])) continue;
+        nsecond += 1;
+        const uint32_t g = point_list[k];
+        const R co = conic_opacity[4 * g + 3];
+        const R depth_center = ts[g];
+        const R dpx = ray_planes[2 * g], dpy = ray_planes[2 * g + 1];
+        const R mx = means2D[2 * g], my = means2D[2 * g + 1];
+        const R* ic = &invraycov[6 * g];
+        M3<R> inv(ic[0], ic[1], ic[2], ic[1], ic[3], ic[4], ic[2], ic[4], ic[5]);
+        for (int i = 0; i < num_projected; i++) {
+          const R dx = mx - pxy[i][0], dy = my - pxy[i][1];
+          const R depth = depth_center + (dpx * dx + dpy * dy);
+          R alpha;
+          if (condition[g]) {
+            V3<R> du{dx, dy, depth_center - std::fmin(pdepth[i], depth)};
+            R power = R(-0.5f) * (dot(du, inv * du));
+            alpha = std::fmin(R(0.99f), co * exp_spec(std::fmin(power, R(80.0f))));
+          } else {
+            if (pdepth[i] < depth) alpha = 0;
+            else {
+              V3<R> du{dx, dy, depth_center};
+              R power = R(-0.5f) * (dot(du, inv * du));
+              alpha = std::fmin(R(0.99f), co * exp_spec(std::fmin(power, R(80.0f))));
+            }
+          }
+          if (alpha < R(1.0f) / R(255.0f)) continue;
+          const R test_T = pT[i] * (1 - alpha);
+          palpha[i] += alpha * pT[i];
+          pT[i] = test_T;
+        }
+      }
+      for (int i = 0; i < num_projected; i++) {
+        out_alpha_integrated[pid[i]] = palpha[i];
+        for (int ch = 0; ch < 3; ch++) out_color_integrated[3 * pid[i] + ch] = C[ch] + T * bg[ch];
+        out_coordinate2d[2 * pid[i]] = pxy[i][0];
+        out_coordinate2d[2 * pid[i] + 1] = pxy[i][1];
+        if (pdepth[i] > 0) {
+          const R dx = mid_mean2d[0] - pxy[i][0], dy = mid_mean2d[1] - pxy[i][1];
+          const R depth = mid_depth_center + (mid_plane[0] * dx + mid_plane[1] * dy);
+          out_sdf[pid[i]] = depth - pdepth[i];
+        }
+      }
+      if (!exceed) break;
+    }
+    out9[8 * HW + pix_id] = static_cast<R>(total_projected);
+  }
+
+  // Rasterizer::integrate, rasterizer_impl.cu:573-843 (+ the output fills of rasterize_points.cu:312-320)
+  int integrate(const R* pts, int npts) {
+    inte = true;
+    PN = npts;
+    points3D.assign(pts, pts + 3 * size_t(npts));
+    focal_y = H / (R(2.0f) * tan_fovy);
+    focal_x = W / (R(2.0f) * tan_fovx);
+    gx = (W + TILE - 1) / TILE;
+    gy = (H + TILE - 1) / TILE;
+    const size_t HW = size_t(H) * W;
+    auto z = [&](std::vector<R>& v, size_t n) { v.assign(n, R(0)); };
+    z(depths, P); z(camera_planes, 6 * size_t(P)); z(ray_planes, 2 * size_t(P)); z(ts, P); z(normals, 3 * size_t(P));
+    z(means2D, 2 * size_t(P)); z(view_points, 3 * size_t(P)); z(cov3D, 6 * size_t(P)); z(conic_opacity, 4 * size_t(P)); z(rgb, 3 * size_t(P));
+    z(invraycov, 6 * size_t(P)); condition.assign(P, 0);
+    clamped.assign(3 * size_t(P), 0); radii.assign(P, 0); tiles_touched.assign(P, 0); point_offsets.assign(P, 0);
+    ranges.assign(2 * size_t(gx) * gy, 0); point_ranges.assign(2 * size_t(gx) * gy, 0);
+    n_contrib.assign(2 * HW, 0);
+    z(out9, 9 * HW); z(final_T, HW);
+    out_alpha_integrated.assign(PN, R(1.0)); z(out_color_integrated, 3 * size_t(PN)); z(out_coordinate2d, 2 * size_t(PN));
+    out_sdf.assign(PN, R(-1000.0));
+    z(points2D, 2 * size_t(PN)); z(point_depths, PN); point_tiles.assign(PN, 0);
+    num_rendered = 0;
+    if (P != 0 && PN != 0) {
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(nthreads)
+      for (int i = 0; i < P; i++) preprocess_one(i);
+      bin_and_sort();
+      // preprocessPointsCUDA, forward.cu:855-900
+      for (int i = 0; i < PN; i++) {
+        V3<R> p{points3D[3 * i], points3D[3 * i + 1], points3D[3 * i + 2]};
+        V3<R> pv = xform_point43(p, view);
+        if (pv.z <= R(0.2f)) continue;
+        const R ix = static_cast<R>(static_cast<double>(focal_x * pv.x / (pv.z + R(0.0000001f))) + W / 2.);
+        const R iy = static_cast<R>(static_cast<double>(focal_y * pv.y / (pv.z + R(0.0000001f))) + H / 2.);
+        if (ix < 0 || ix >= W || iy < 0 || iy >= H) continue;
+        point_depths[i] = std::sqrt(pv.x * pv.x + pv.y * pv.y + pv.z * pv.z);
+        points2D[2 * i] = ix; points2D[2 * i + 1] = iy;
+        point_tiles[i] = 1;
+      }
+      // createWithKeys + SortPairs + identifyTileRanges, rasterizer_impl.cu:114-145,784-806
+      std::vector<std::pair<uint64_t, uint32_t>> kv;
+      for (int i = 0; i < PN; i++) {
+        if (!point_tiles[i]) continue;
+        int tx = std::min(gx - 1, std::max(0, to_int_sat(points2D[2 * i] / R(TILE))));
+        int ty = std::min(gy - 1, std::max(0, to_int_sat(points2D[2 * i + 1] / R(TILE))));
+        float df = static_cast<float>(point_depths[i]);
+        uint32_t dbits;
+        std::memcpy(&dbits, &df, 4);
+        kv.push_back({(static_cast<uint64_t>(ty) * gx + tx) << 32 | dbits, static_cast<uint32_t>(i)});
+      }
+      std::stable_sort(kv.begin(), kv.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+      pt_list.resize(kv.size());
+      for (size_t i = 0; i < kv.size(); i++) {
+        pt_list[i] = kv[i].second;
+        uint32_t cur = kv[i].first >> 32;
+        if (i == 0) point_ranges[2 * cur] = 0;
+        else {
+          uint32_t prev = kv[i - 1].first >> 32;
+          if (cur != prev) { point_ranges[2 * prev + 1] = i; point_ranges[2 * cur] = i; }
+        }
+        if (i + 1 == kv.size()) point_ranges[2 * cur + 1] = kv.size();
+      }
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+      for (int tile = 0; tile < gx * gy; tile++) {
+        const int ty = tile / gx, tx = tile % gx;
+        for (int y = ty * TILE; y < std::min((ty + 1) * TILE, H); y++)
+          for (int x = tx * TILE; x < std::min((tx + 1) * TILE, W); x++) integrate_pixel(x, y);
+      }
+    }
+    inte = false;
     register_all();
     return num_rendered;
   }
@@ -990,6 +1232,8 @@ template <class R> struct Oracle {
     REG(out_color); REG(out_coord); REG(out_mcoord); REG(out_depth); REG(out_mdepth); REG(out_alpha); REG(out_normal);
     REG(dL_dmeans3D); REG(dL_dview_points); REG(dL_dmeans2D); REG(dL_dcolors); REG(dL_dts); REG(dL_dcamera_planes);
     REG(dL_dray_planes); REG(dL_dnormals); REG(dL_dconic); REG(dL_dopacity); REG(dL_dcov3D); REG(dL_dsh); REG(dL_dscales);
+    REG(invraycov); REG(condition); REG(points2D); REG(point_depths); REG(point_ranges); REG(out9); REG(final_T);
+    REG(out_alpha_integrated); REG(out_color_integrated); REG(out_coordinate2d); REG(out_sdf); REG(pt_list);
     REG(dL_drotations); REG(acc_dmeans2D); REG(acc_dconic); REG(acc_dopacity); REG(acc_dcolors);
 #undef REG
   }
@@ -1079,6 +1323,13 @@ long long oracle_get(void* hv, const char* name, void* dst, long long nbytes) {
   const long long sz = static_cast<long long>(it->second.second);
   if (dst) std::memcpy(dst, it->second.first, static_cast<size_t>(std::min(sz, nbytes)));
   return sz;
+}
+
+// points: element type of `precision`; returns num_rendered.  Outputs via oracle_get: out9 [9,H,W], final_T,
+// out_alpha_integrated [PN], out_color_integrated [PN,3], out_coordinate2d [PN,2], out_sdf [PN], radii, invraycov, condition.
+int oracle_integrate(void* hv, int PN, const void* points3D) {
+  auto* h = static_cast<Handle*>(hv);
+  return h->d ? h->d->integrate((const double*)points3D, PN) : h->f->integrate((const float*)points3D, PN);
 }
 
 long long oracle_stat_pairs(void* hv) {

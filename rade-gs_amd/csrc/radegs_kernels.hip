@@ -65,15 +65,17 @@ struct PreFwdArgs {
   CamArgs cam;
   int write_b;
   int* radii; float4* splat_a; float4* splat_b; uint32_t* tiles_touched; uint32_t* depth_key; uint8_t* clamped;
+  float4* inte_rec;  // [P][2] {icr0..icr3 | icr4, icr5, well, 0}; INTE kernel only
 };
 
+template <bool INTE>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(const PreFwdArgs a) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= a.P) return;
   const Camera cam = load_camera(a.cam);
   SplatFwd s;
   const float* m = a.means3D + 3 * (size_t)idx;
-  preprocess_fwd(mk3(m[0], m[1], m[2]), a.scales ? a.scales + 3 * (size_t)idx : nullptr,
+  preprocess_fwd<INTE>(mk3(m[0], m[1], m[2]), a.scales ? a.scales + 3 * (size_t)idx : nullptr,
                  a.rotations ? a.rotations + 4 * (size_t)idx : nullptr, a.cov3D_precomp ? a.cov3D_precomp + 6 * (size_t)idx : nullptr,
                  a.opacities[idx], a.D, a.shs ? a.shs + (size_t)idx * a.M * 3 : nullptr,
                  a.colors_precomp ? a.colors_precomp + 3 * (size_t)idx : nullptr, cam, s);
@@ -94,6 +96,11 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(const PreFwdArgs a)
       rb[2] = make_float4(s.vp[2], 0.f, 0.f, 0.f);
     }
     a.clamped[idx] = (uint8_t)s.clamped;
+    if constexpr (INTE) {
+      float4* ri = a.inte_rec + 2 * (size_t)idx;
+      ri[0] = make_float4(s.icr[0], s.icr[1], s.icr[2], s.icr[3]);
+      ri[1] = make_float4(s.icr[4], s.icr[5], s.well ? 1.0f : 0.0f, 0.f);
+    }
   }
 }
 
@@ -180,6 +187,265 @@ __device__ __forceinline__ bool entry_may_touch(const float4 q0, const float4 q1
   const float hy = sqrtf(r * cx) * 1.001f + 0.01f;
   const bool off = (mx + hx < x_lo) || (mx - hx > x_hi) || (my + hy < y_lo) || (my - hy > y_hi) || (thr > 0.0f);
   return !off;
+}
+
+__device__ __forceinline__ int xcd_band_remap(int b, int n);
+
+// ============================================================================ integrate ==
+// GaussianRasterizer.integrate (GOF-style point integration used by mesh extraction): for every query point that
+// projects into the image, the opacity accumulated along its pixel's ray up to the point.
+//   preprocessPointsCUDA  DGR/cuda_rasterizer/forward.cu:855-900   -> points_preprocess_kernel
+//   createWithKeys + SortPairs + identifyTileRanges (rasterizer_impl.cu:114-145,784-806)
+//                                                                   -> per-PIXEL counting sort (count / scan / scatter)
+//   integrateCUDA         forward.cu:938-1372                       -> integrate_kernel
+// Re-design: the reference bins points per 16x16 tile and lets every pixel thread scan its tile's whole point list to
+// find its own points (two per-thread local arrays of 2048 + 5x256 entries).  A point belongs to exactly one pixel
+// (floor of its projection) and points do not interact, so they are binned per pixel here: each lane gets the [start,end)
+// range of its own points, the 2048-entry "contributed" list is replaced by replaying the 5-sample transmittance test
+// (identical arithmetic => identical decisions), and no per-thread scratch arrays exist at all.
+struct PointsPreArgs {
+  int PN; const float* points3D; const float* view; float focal_x, focal_y; int W, H;
+  float2* p2d; float* pdepth; uint32_t* ppix; uint32_t* pix_count;
+  float* out_alpha_integrated; float* out_color_integrated; float* out_coordinate2d; float* out_sdf;
+};
+
+// initial values of rasterize_points.cu:312-320
+__device__ __forceinline__ void point_outputs_init(const PointsPreArgs& a, int i) {
+  a.out_alpha_integrated[i] = 1.0f;
+  a.out_color_integrated[3 * (size_t)i] = 0.f; a.out_color_integrated[3 * (size_t)i + 1] = 0.f; a.out_color_integrated[3 * (size_t)i + 2] = 0.f;
+  a.out_coordinate2d[2 * (size_t)i] = 0.f; a.out_coordinate2d[2 * (size_t)i + 1] = 0.f;
+  a.out_sdf[i] = -1000.0f;
+}
+__global__ void __launch_bounds__(256) points_init_kernel(const PointsPreArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < a.PN) point_outputs_init(a, i);
+}
+
+__global__ void __launch_bounds__(256) points_preprocess_kernel(const PointsPreArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.PN) return;
+  point_outputs_init(a, i);
+  a.ppix[i] = 0xFFFFFFFFu;
+  const float* p = a.points3D + 3 * (size_t)i;
+  const v3 pv = xform43(mk3(p[0], p[1], p[2]), a.view);
+  if (pv.z <= 0.2f) return;
+  const float ix = (float)((double)(a.focal_x * pv.x / (pv.z + 0.0000001f)) + a.W / 2.);
+  const float iy = (float)((double)(a.focal_y * pv.y / (pv.z + 0.0000001f)) + a.H / 2.);
+  if (ix < 0 || ix >= a.W || iy < 0 || iy >= a.H) return;
+  a.pdepth[i] = sqrtf(pv.x * pv.x + pv.y * pv.y + pv.z * pv.z);
+  a.p2d[i] = make_float2(ix, iy);
+  const uint32_t pix = (uint32_t)f2i_sat(floorf(iy)) * (uint32_t)a.W + (uint32_t)f2i_sat(floorf(ix));
+  a.ppix[i] = pix;
+  atomicAdd(&a.pix_count[pix], 1u);
+}
+
+// slot = incl[pix] - (old remaining count): distinct slots inside the pixel's range, no second cursor array
+__global__ void __launch_bounds__(256) points_scatter_kernel(int PN, const uint32_t* ppix, uint32_t* pix_count, const uint32_t* pix_incl,
+                                                            uint32_t* pt_sorted) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= PN) return;
+  const uint32_t pix = ppix[i];
+  if (pix == 0xFFFFFFFFu) return;
+  const uint32_t rem = atomicSub(&pix_count[pix], 1u);
+  pt_sorted[pix_incl[pix] - rem] = (uint32_t)i;
+}
+
+struct IntegrateArgs {
+  const uint2* ranges; const uint32_t* point_list; const float4* splat_a; const float4* inte_rec;
+  int W, H, gx; const float* bg;
+  const uint32_t* pix_incl; const uint32_t* pt_sorted; const float2* p2d; const float* pdepth;
+  float* out9; float* final_T; uint32_t* n_contrib;
+  float* out_alpha_integrated; float* out_color_integrated; float* out_coordinate2d; float* out_sdf;
+};
+
+constexpr int kMaxContributors = 512 * 4;  // MAX_NUM_CONTRIBUTORS * 4, auxiliary.h:27 / forward.cu:1003
+constexpr int kPointsPerPass = 4;
+
+// The 5-sample (centre + 4 corners) transmittance test of forward.cu:1043-1110 for one list entry; updates cT and
+// reports which samples passed.  Returns true when any did ("used").
+struct FiveSample { float alpha0, depth0, depth_max; bool pass0; };
+__device__ __forceinline__ bool five_sample(const float4 A, const float4 B, float rpx, float rpy, float pixfx, float pixfy, float cT[5],
+                                            FiveSample& o) {
+  const float offx[5] = {0.0f, -0.5f, 0.5f, -0.5f, 0.5f}, offy[5] = {0.0f, -0.5f, -0.5f, 0.5f, 0.5f};
+  bool used = false;
+  o.pass0 = false;
+  o.depth_max = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < 5; c++) {
+    const float dx = A.x - pixfx - offx[c], dy = A.y - pixfy - offy[c];
+    const float depth = B.w + (rpx * dx + rpy * dy);
+    const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+    if (power > 0.0f || power < B.z) continue;  // B.z: conservative exponent threshold for alpha < 1/255
+    const float alpha = fminf(0.99f, B.y * exp_spec(power));
+    if (alpha < 1.0f / 255.0f) continue;
+    const float test_T = cT[c] * (1 - alpha);
+    if (test_T < 0.0001f) continue;
+    if (c == 0) { o.pass0 = true; o.alpha0 = alpha; o.depth0 = depth; }
+    o.depth_max = fmaxf(o.depth_max, depth);
+    cT[c] = test_T;
+    used = true;
+  }
+  return used;
+}
+
+__global__ void __launch_bounds__(64) integrate_kernel(const IntegrateArgs a) {
+  __shared__ float4 lds_a[64 * 4];
+  __shared__ float4 lds_i[64 * 2];
+  const int item = xcd_band_remap(blockIdx.x, gridDim.x);
+  const int tile = item >> 2, sub = item & 3;
+  const int tile_x = tile % a.gx, tile_y = tile / a.gx;
+  const int lane = threadIdx.x, lx = lane & 15, lr = lane >> 4;
+  const int px = tile_x * 16 + lx, py = tile_y * 16 + sub * 4 + lr;
+  const int W = a.W, H = a.H;
+  const size_t HW = (size_t)H * W;
+  const bool inside = px < W && py < H;
+  const size_t pix = (size_t)py * W + px;
+  const float pixfx = (float)px + 0.5f, pixfy = (float)py + 0.5f;
+  // sample positions of this wave's strip (pixel centres +- 0.5) for the batch cull
+  const float reg_x0 = (float)(tile_x * 16), reg_x1 = reg_x0 + 16.0f;
+  const float reg_y0 = (float)(tile_y * 16 + sub * 4), reg_y1 = reg_y0 + 4.0f;
+  const uint2 range = a.ranges[tile];
+  const int n = (int)(range.y - range.x);
+
+  // ---------------------------------------------------------------- phase 1: the image ----
+  float cT[5] = {1.f, 1.f, 1.f, 1.f, 1.f};  // cT[0] is the pixel's T
+  float C0 = 0.f, C1 = 0.f, C2 = 0.f, C3 = 0.f, C4 = 0.f, C6 = 0.f, C7 = 0.f;
+  float mid_dc = 0.f, mid_px = 0.f, mid_py = 0.f, mid_mx = 0.f, mid_my = 0.f;
+  uint32_t last_c = 0, n_local = 0;
+  bool done = !inside;
+  for (int base = 0; base < n; base += 64) {
+    if (__all(done)) break;
+    __syncthreads();
+    const int k = base + lane;
+    bool rel_lane = false;
+    if (k < n) {
+      const uint32_t g = a.point_list[range.x + k];
+      const float4* src = a.splat_a + 4 * (size_t)g;
+      const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+      lds_a[lane * 4 + 0] = q0; lds_a[lane * 4 + 1] = q1; lds_a[lane * 4 + 2] = q2; lds_a[lane * 4 + 3] = q3;
+      rel_lane = entry_may_touch(q0, q1, reg_x0, reg_x1, reg_y0, reg_y1);
+    }
+    uint64_t rel = __ballot(rel_lane);
+    __syncthreads();
+    while (rel != 0) {
+      const int j = __builtin_ctzll(rel);
+      rel &= rel - 1;
+      if (done) continue;
+      const float4 A = lds_a[j * 4 + 0], B = lds_a[j * 4 + 1], Cc = lds_a[j * 4 + 2], D = lds_a[j * 4 + 3];
+      const float T = cT[0];
+      FiveSample f;
+      if (!five_sample(A, B, Cc.w, D.x, pixfx, pixfy, cT, f)) continue;
+      if (f.pass0) {
+        C0 += Cc.x * f.alpha0 * T; C1 += Cc.y * f.alpha0 * T; C2 += Cc.z * f.alpha0 * T;
+      }
+      if (f.depth_max > C6) C6 = f.depth_max;
+      if (f.pass0) {
+        C7 += f.alpha0 * T;
+        C3 += f.depth0 * f.alpha0 * T;
+        if (T > 0.5f) { C4 = f.depth0; mid_dc = B.w; mid_px = Cc.w; mid_py = D.x; mid_mx = A.x; mid_my = A.y; }
+      }
+      last_c = (uint32_t)(base + j + 1);
+      n_local += 1;
+      if (n_local >= (uint32_t)kMaxContributors) done = true;  // the reference stops this pixel here (forward.cu:1121-1125)
+    }
+  }
+  const float T = cT[0];
+  float col0 = 0.f, col1 = 0.f, col2 = 0.f;
+  if (inside) {
+    col0 = C0 + T * a.bg[0]; col1 = C1 + T * a.bg[1]; col2 = C2 + T * a.bg[2];
+    a.final_T[pix] = T;
+    a.n_contrib[pix] = last_c;
+    a.out9[0 * HW + pix] = col0; a.out9[1 * HW + pix] = col1; a.out9[2 * HW + pix] = col2;
+    a.out9[3 * HW + pix] = C3; a.out9[4 * HW + pix] = C4; a.out9[6 * HW + pix] = C6; a.out9[7 * HW + pix] = C7;
+  }
+
+  // --------------------------------------------------- phase 2: this pixel's query points ----
+  uint32_t cur = 0, pe = 0;
+  if (inside) {
+    cur = pix == 0 ? 0u : a.pix_incl[pix - 1];
+    pe = a.pix_incl[pix];
+    a.out9[8 * HW + pix] = (float)(pe - cur);
+  }
+  while (__any(cur < pe)) {
+    const int np = (int)min((uint32_t)kPointsPerPass, pe - cur);
+    uint32_t pid[kPointsPerPass];
+    float qx[kPointsPerPass], qy[kPointsPerPass], qd[kPointsPerPass], pa[kPointsPerPass], pT[kPointsPerPass];
+#pragma unroll
+    for (int i = 0; i < kPointsPerPass; i++) {
+      pid[i] = 0; qx[i] = qy[i] = qd[i] = 0.f; pa[i] = 0.f; pT[i] = 1.f;
+      if (i < np) {
+        pid[i] = a.pt_sorted[cur + i];
+        const float2 q = a.p2d[pid[i]];
+        qx[i] = q.x; qy[i] = q.y; qd[i] = a.pdepth[pid[i]];
+      }
+    }
+    float rT[5] = {1.f, 1.f, 1.f, 1.f, 1.f};
+    const uint32_t my_last = np > 0 ? last_c : 0u;
+    for (int base = 0; base < n; base += 64) {
+      if (__all((uint32_t)base >= my_last)) break;
+      __syncthreads();
+      const int k = base + lane;
+      bool rel_lane = false;
+      if (k < n) {
+        const uint32_t g = a.point_list[range.x + k];
+        const float4* src = a.splat_a + 4 * (size_t)g;
+        const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+        lds_a[lane * 4 + 0] = q0; lds_a[lane * 4 + 1] = q1; lds_a[lane * 4 + 2] = q2; lds_a[lane * 4 + 3] = q3;
+        const float4* si = a.inte_rec + 2 * (size_t)g;
+        lds_i[lane * 2 + 0] = si[0]; lds_i[lane * 2 + 1] = si[1];
+        rel_lane = entry_may_touch(q0, q1, reg_x0, reg_x1, reg_y0, reg_y1);
+      }
+      uint64_t rel = __ballot(rel_lane);
+      __syncthreads();
+      while (rel != 0) {
+        const int j = __builtin_ctzll(rel);
+        rel &= rel - 1;
+        if ((uint32_t)(base + j + 1) > my_last) continue;
+        const float4 A = lds_a[j * 4 + 0], B = lds_a[j * 4 + 1], Cc = lds_a[j * 4 + 2], D = lds_a[j * 4 + 3];
+        FiveSample f;
+        if (!five_sample(A, B, Cc.w, D.x, pixfx, pixfy, rT, f)) continue;
+        const float4 I0 = lds_i[j * 2 + 0], I1 = lds_i[j * 2 + 1];
+        const m3 inv = mk33(I0.x, I0.y, I0.z, I0.y, I0.w, I1.x, I0.z, I1.x, I1.y);
+        const bool cond = I1.z != 0.0f;
+#pragma unroll
+        for (int i = 0; i < kPointsPerPass; i++) {
+          if (i >= np) continue;
+          const float dx = A.x - qx[i], dy = A.y - qy[i];
+          const float depth = B.w + (Cc.w * dx + D.x * dy);
+          float alpha;
+          if (cond) {
+            const v3 du = mk3(dx, dy, B.w - fminf(qd[i], depth));
+            const float power = -0.5f * dot(du, mul(inv, du));
+            alpha = fminf(0.99f, B.y * exp_spec(fminf(power, 80.0f)));
+          } else if (qd[i] < depth) {
+            alpha = 0.f;
+          } else {
+            const v3 du = mk3(dx, dy, B.w);
+            const float power = -0.5f * dot(du, mul(inv, du));
+            alpha = fminf(0.99f, B.y * exp_spec(fminf(power, 80.0f)));
+          }
+          if (alpha < 1.0f / 255.0f) continue;
+          const float test_T = pT[i] * (1 - alpha);
+          pa[i] += alpha * pT[i];
+          pT[i] = test_T;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kPointsPerPass; i++) {
+      if (i >= np) continue;
+      const size_t q = pid[i];
+      a.out_alpha_integrated[q] = pa[i];
+      a.out_color_integrated[3 * q] = col0; a.out_color_integrated[3 * q + 1] = col1; a.out_color_integrated[3 * q + 2] = col2;
+      a.out_coordinate2d[2 * q] = qx[i]; a.out_coordinate2d[2 * q + 1] = qy[i];
+      if (qd[i] > 0) {
+        const float dx = mid_mx - qx[i], dy = mid_my - qy[i];
+        const float depth = mid_dc + (mid_px * dx + mid_py * dy);
+        a.out_sdf[q] = depth - qd[i];
+      }
+    }
+    cur += (uint32_t)np;
+  }
 }
 
 // =========================================================================== blend, fwd ==

@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(kSortThreads) gather_block_sums_kernel(const u
   for (int k = 0; k < kScanItems; k++) {
     const uint32_t i = base + k;
     if (i < n) {
-      const uint32_t v = vals[idx[i]];  // the only random gather; the scan pass re-reads it sequentially
+      const uint32_t v = vals[idx ? idx[i] : i];  // the only random gather; the scan pass re-reads it sequentially
       gathered[i] = v;
       s += v;
     }
@@ -303,7 +303,7 @@ size_t scan_temp_bytes(size_t n) {
   return ((n + kSortThreads * kScanItems - 1) / (kSortThreads * kScanItems) + 1) * sizeof(uint32_t) + 512 + n * sizeof(uint32_t);
 }
 
-// out[i] = sum_{j <= i} vals[idx[j]]   (rasterizer_impl.cu:350's InclusiveSum, taken in depth order)
+// out[i] = sum_{j <= i} vals[idx[j]]   (rasterizer_impl.cu:350's InclusiveSum, taken in depth order); idx == nullptr: identity
 hipError_t inclusive_scan_gather_u32(void* temp, size_t temp_bytes, const uint32_t* vals, const uint32_t* idx, uint32_t* out, size_t n,
                                      hipStream_t stream) {
   if (n == 0) return hipSuccess;

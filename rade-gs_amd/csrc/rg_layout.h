@@ -115,6 +115,39 @@ struct ImageState {
   }
 };
 
+// State of the integrate() path beyond the three buffers above (the reference's fourth and fifth resizable buffers,
+// rasterize_points.cu:303-309: PointState / point binning): the INTE preprocess record, the projected query points and
+// their per-PIXEL bins.
+struct PointState {
+  float* inte_rec;       // [P*8]  {icr0..icr5, well, 0}: inverse ray-space covariance (upper triangle) + conditioning flag
+  float* p2d;            // [PN*2] projected position (pixels)
+  float* pdepth;         // [PN]   |p_view|
+  uint32_t* ppix;        // [PN]   pixel index or 0xFFFFFFFF (not projected)
+  uint32_t* pt_sorted;   // [PN]   point ids grouped by pixel
+  uint32_t* pix_count;   // [H*W]
+  uint32_t* pix_incl;    // [H*W]  inclusive scan of pix_count
+  float* final_T;        // [H*W]
+  char* temp;
+  size_t temp_bytes;
+  size_t total;
+  static PointState carve(void* buf, size_t P, size_t PN, size_t HW, size_t temp_bytes) {
+    Carver c(buf);
+    PointState s;
+    s.inte_rec = c.take<float>(P * 8);
+    s.p2d = c.take<float>(PN * 2);
+    s.pdepth = c.take<float>(PN);
+    s.ppix = c.take<uint32_t>(PN);
+    s.pt_sorted = c.take<uint32_t>(PN);
+    s.pix_count = c.take<uint32_t>(HW);
+    s.pix_incl = c.take<uint32_t>(HW);
+    s.final_T = c.take<float>(HW);
+    s.temp = c.take<char>(temp_bytes);
+    s.temp_bytes = temp_bytes;
+    s.total = c.total();
+    return s;
+  }
+};
+
 // Per-Gaussian gradient accumulator record written by the blend backward with one 16/25-lane
 // atomic instruction: floats in rg::SplatAcc order; 16 per Gaussian without the coord map
 // (64 B = one line), 32 with it.

@@ -139,6 +139,10 @@ struct SplatFwd {
   float cp[6];          // camera-space coord gradient per pixel (3x2)
   float vp[3];          // view-space mean
   unsigned clamped;     // bit c set <=> channel c was clamped at 0
+  // INTE only (the integrate() path): inverse covariance in ray space (u/f, v/f, t), upper triangle, and whether the
+  // 3D covariance was well conditioned (computeCov2D<true>, forward.cu:187-235)
+  float icr[6];
+  bool well;
 };
 
 // SH -> RGB (+0.5, clamp at 0, remember which channels clamped).  sh points at this
@@ -175,6 +179,7 @@ RG_HD void sh_to_rgb(int deg, const float* sh, v3 pos, const float campos[3], fl
 
 // One Gaussian.  cov3D_in: precomputed covariance (6) or nullptr; scale/quat used otherwise.
 // sh: this Gaussian's SH block or nullptr; color_in: precomputed RGB (3) or nullptr.
+template <bool INTE = false>
 RG_HD void preprocess_fwd(v3 p_orig, const float* scale3, const float* quat4, const float* cov3D_in, float opacity,
                           int deg, const float* sh, const float* color_in, const Camera& cam, SplatFwd& o) {
   o.radius = 0;
@@ -209,6 +214,10 @@ RG_HD void preprocess_fwd(v3 p_orig, const float* scale3, const float* quat4, co
     for (int i = 0; i < 6; i++) o.cp[i] = 0;
     o.nrm[0] = o.nrm[1] = o.nrm[2] = 0;
     o.rp[0] = o.rp[1] = 0;
+    if constexpr (INTE) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) o.icr[i] = 0;  // the reference leaves its zero-filled tensor untouched here
+    }
   } else {
     const v3 t = g.t;
     const float txtz = g.txtz, tytz = g.tytz;
@@ -232,7 +241,25 @@ RG_HD void preprocess_fwd(v3 p_orig, const float* scale3, const float* quat4, co
     v3 ray_n = mk3(-plane.x * factor_normal, -plane.y * factor_normal, -1.0f);
     v3 n = normalize(mul(nJ, ray_n));
     o.nrm[0] = n.x; o.nrm[1] = n.y; o.nrm[2] = n.z;
+    if constexpr (INTE) {
+      m3 icr;
+      if (g.well) {
+        const float ltz = u2 + v2 + 1;
+        m3 full = mk33(v2 + 1, -uv, txtz / l * ltz, -uv, u2 + 1, tytz / l * ltz, -txtz, -tytz, 1 / l * ltz);
+        m3 T2 = mul(g.W, transpose(scale_l(t.z / (u2 + v2 + 1), full)));
+        icr = mul(mul(transpose(T2), g.Vinv), T2);
+      } else {
+        // Upstream's shadowed `inv_cov_ray` (forward.cu:223) leaves the matrix that is stored UNINITIALISED in this
+        // branch, and the value it discards is 1/rounding-noise.  Defined as zero here (include/radegs.h).
+        icr = zero33();
+      }
+      m3 sc = mk33(1 / cam.focal_x, 0.f, 0.f, 0.f, 1 / cam.focal_y, 0.f, 0.f, 0.f, 1.f);
+      icr = mul(mul(sc, icr), sc);
+      o.icr[0] = icr.c[0][0]; o.icr[1] = icr.c[0][1]; o.icr[2] = icr.c[0][2];
+      o.icr[3] = icr.c[1][1]; o.icr[4] = icr.c[1][2]; o.icr[5] = icr.c[2][2];
+    }
   }
+  if constexpr (INTE) o.well = g.well;
 
   o.ts = sqrtf(p_view.x * p_view.x + p_view.y * p_view.y + p_view.z * p_view.z);
   const float det = (cvx * cvz - cvy * cvy);

@@ -4,14 +4,13 @@ reference's pybind module (DGR/ext.cpp:15-19):
     rasterize_gaussians(...)            DGR/rasterize_points.h:18-42  / rasterize_points.cu:36-133
     rasterize_gaussians_backward(...)   DGR/rasterize_points.h:43-76  / rasterize_points.cu:136-246
     mark_visible(...)                   DGR/rasterize_points.h:78-81  / rasterize_points.cu:248-267
+    integrate_gaussians_to_points(...)  DGR/rasterize_points.h:83-110 / rasterize_points.cu:269-388
 
 Same positional arguments, same return tuples (note the forward's output order differs from the
 Python operator's 8-tuple, exactly as upstream).  torch is used for device memory and the current
 HIP stream only; no torch type crosses the C boundary.
 
 There is NO CPU path and no fallback: a missing library or a non-GPU tensor raises.
-`integrate_gaussians_to_points` (marching-tetrahedra extraction) is not built yet and
-raises NotImplementedError.
 """
 import ctypes
 import os
@@ -59,8 +58,21 @@ class RadegsBwdArgs(ctypes.Structure):
                 ("require_coord", ctypes.c_int), ("require_depth", ctypes.c_int), ("debug", ctypes.c_int)]
 
 
+class RadegsIntegrateArgs(ctypes.Structure):
+    _fields_ = [("P", ctypes.c_int), ("D", ctypes.c_int), ("M", ctypes.c_int), ("PN", ctypes.c_int), ("width", ctypes.c_int),
+                ("height", ctypes.c_int),
+                ("background", ctypes.c_void_p), ("means3D", ctypes.c_void_p), ("shs", ctypes.c_void_p),
+                ("colors_precomp", ctypes.c_void_p), ("opacities", ctypes.c_void_p), ("scales", ctypes.c_void_p),
+                ("rotations", ctypes.c_void_p), ("cov3D_precomp", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p),
+                ("projmatrix", ctypes.c_void_p), ("cam_pos", ctypes.c_void_p), ("points3D", ctypes.c_void_p),
+                ("scale_modifier", ctypes.c_float), ("tan_fovx", ctypes.c_float), ("tan_fovy", ctypes.c_float),
+                ("kernel_size", ctypes.c_float), ("debug", ctypes.c_int),
+                ("out_color", ctypes.c_void_p), ("out_alpha_integrated", ctypes.c_void_p), ("out_color_integrated", ctypes.c_void_p),
+                ("out_coordinate2d", ctypes.c_void_p), ("out_sdf", ctypes.c_void_p), ("radii", ctypes.c_void_p)]
+
+
 # every symbol include/radegs.h declares
-EXPORTED_SYMBOLS = ("radegs_forward", "radegs_backward", "radegs_mark_visible", "radegs_geometry_bytes", "radegs_image_bytes",
+EXPORTED_SYMBOLS = ("radegs_forward", "radegs_backward", "radegs_mark_visible", "radegs_integrate", "radegs_geometry_bytes", "radegs_image_bytes",
                     "radegs_binning_bytes", "radegs_debug_export", "radegs_last_error", "radegs_version", "radegs_profile_enable",
                     "radegs_profile_num_stages", "radegs_profile_stage_name", "radegs_profile_collect")
 
@@ -68,6 +80,7 @@ _lib = None
 # test hook: when True, the per-Gaussian accumulation scratch of the last backward is kept in LAST_ACC
 KEEP_ACC = False
 LAST_ACC = None
+LAST_POINT_STATE = None
 # Optional allocator for the 8 gradient tensors of the backward: callable(name, shape, dtype, device) -> tensor
 # or None.  A data-parallel caller points it at slices of ONE flat bucket so that the gradient all-reduce needs no
 # gather copy (rade-gs_amd/view_parallel.GradBucket).  Default: plain torch.empty.
@@ -87,6 +100,8 @@ def library():
                                      ctypes.c_void_p, ctypes.c_void_p]
         L.radegs_backward.restype = ctypes.c_int
         L.radegs_backward.argtypes = [ctypes.POINTER(RadegsBwdArgs), _ALLOC_FN, ctypes.c_void_p, ctypes.c_void_p]
+        L.radegs_integrate.restype = ctypes.c_int
+        L.radegs_integrate.argtypes = [ctypes.POINTER(RadegsIntegrateArgs)] + [_ALLOC_FN, ctypes.c_void_p] * 4 + [ctypes.c_void_p]
         L.radegs_mark_visible.restype = ctypes.c_int
         L.radegs_mark_visible.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.radegs_geometry_bytes.restype = ctypes.c_size_t
@@ -278,9 +293,49 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     return present
 
 
-def integrate_gaussians_to_points(*_args, **_kwargs):
-    raise NotImplementedError("integrate_gaussians_to_points (GOF point integration for marching tetrahedra, "
-                              "DGR/rasterize_points.cu:269-388) is outside the hot path built so far -- SURVEY.md 8(f) N1")
+def integrate_gaussians_to_points(background, points3D, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                                  view2gaussian_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset,
+                                  image_height, image_width, sh, degree, campos, prefiltered, debug):
+    """IntegrateGaussiansToPointsCUDA (DGR/rasterize_points.cu:269-388).  `view2gaussian_precomp`, `subpixel_offset` and
+    `prefiltered` are accepted and -- exactly as upstream's kernels do -- never read.  Returns the upstream 10-tuple
+    (num_rendered, out_color[9,H,W], out_alpha_integrated[PN], out_color_integrated[PN,3], out_coordinate2d[PN,2],
+    out_sdf[PN], radii[P], geomBuffer, binningBuffer, imgBuffer); the point-state buffer is dropped like upstream's."""
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    if points3D.dim() != 2 or points3D.size(1) != 3:
+        raise RuntimeError("points3D must have dimensions (num_points, 3)")
+    _require_gpu(means3D, "means3D")
+    _require_gpu(points3D, "points3D")
+    L = library()
+    dev = means3D.device
+    P, PN, H, W = int(means3D.size(0)), int(points3D.size(0)), int(image_height), int(image_width)
+    fo = dict(dtype=torch.float32, device=dev)
+    out_color = torch.empty((9, H, W), **fo)
+    radii = torch.empty(P, dtype=torch.int32, device=dev)
+    out_alpha_integrated = torch.empty((PN,), **fo)
+    out_color_integrated = torch.empty((PN, 3), **fo)
+    out_coordinate2d = torch.empty((PN, 2), **fo)
+    out_sdf = torch.empty((PN,), **fo)
+    geom, binning, img, pts = _Resizable(dev), _Resizable(dev), _Resizable(dev), _Resizable(dev)
+    bg, m3, p3 = _f32(background, "bg"), _f32(means3D, "means3D"), _f32(points3D, "points3D")
+    col, op = _f32(colors, "colors_precomp"), _f32(opacity, "opacities")
+    sc, rot, cov = _f32(scales, "scales"), _f32(rotations, "rotations"), _f32(cov3D_precomp, "cov3D_precomp")
+    vm, pm, cp, shs = _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix"), _f32(campos, "campos"), _f32(sh, "shs")
+    M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
+    a = RadegsIntegrateArgs(P, int(degree), M, PN, W, H, _ptr(bg), _ptr(m3), _ptr(shs), _ptr(col), _ptr(op), _ptr(sc), _ptr(rot),
+                            _ptr(cov), _ptr(vm), _ptr(pm), _ptr(cp), _ptr(p3), float(scale_modifier), float(tan_fovx), float(tan_fovy),
+                            float(kernel_size), int(bool(debug)), _ptr(out_color), _ptr(out_alpha_integrated),
+                            _ptr(out_color_integrated), _ptr(out_coordinate2d), _ptr(out_sdf), _ptr(radii))
+    with torch.cuda.device(dev):
+        rc = L.radegs_integrate(ctypes.byref(a), geom.cb, None, binning.cb, None, img.cb, None, pts.cb, None, _stream(dev))
+    for r in (geom, binning, img, pts):
+        if r.error is not None:
+            raise r.error
+    rendered = _check(rc, "radegs_integrate")
+    global LAST_POINT_STATE
+    LAST_POINT_STATE = pts.tensor if KEEP_ACC else None
+    return (rendered, out_color, out_alpha_integrated, out_color_integrated, out_coordinate2d, out_sdf, radii, geom.tensor,
+            binning.tensor, img.tensor)
 
 
 def debug_export(name, dtype, numel, P, R, W, H, require_coord, geomBuffer, binningBuffer, imageBuffer):

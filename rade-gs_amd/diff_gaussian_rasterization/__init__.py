@@ -128,6 +128,27 @@ class GaussianRasterizer(nn.Module):
 
     def integrate(self, points3D, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                   cov3D_precomp=None, view2gaussian_precomp=None):
-        """GOF point integration used by mesh_extract_tetrahedra.py (upstream :239-306).  Not part of
-        the training/rendering hot path; scheduled as SURVEY.md 8(f) N1."""
-        return _C.integrate_gaussians_to_points()
+        """GOF point integration used by mesh_extract_tetrahedra.py through gaussian_renderer.integrate (upstream :239-306).
+        Returns (color[9,H,W], alpha_integrated[PN], color_integrated[PN,3], point_coordinate[PN,2], point_sdf[PN],
+        radii[P]).  Not differentiable (upstream calls the native function outside any autograd.Function).  Like
+        upstream, the 2D filter is switched off here (kernel_size 0.0) and `means2D` is not used."""
+        rs = self.raster_settings
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        has_sr = scales is not None and rotations is not None
+        any_sr = scales is not None or rotations is not None
+        if (not has_sr and cov3D_precomp is None) or (any_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+        def absent(t):
+            return torch.Tensor([]) if t is None else t
+
+        args = (rs.bg, points3D, means3D, absent(colors_precomp), opacities, absent(scales), absent(rotations), rs.scale_modifier,
+                absent(cov3D_precomp), absent(view2gaussian_precomp), rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
+                0.0,    # kernel_size: hard-coded upstream (:283)
+                None,   # subpixel_offset: upstream allocates an (H,W,2) zero tensor its kernels never read
+                rs.image_height, rs.image_width, absent(shs), rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        # (upstream's debug branch unpacks 8 of the 10 returned values and cannot work; both branches unpack all 10 here)
+        out = _call_native(_C.integrate_gaussians_to_points, args, rs.debug, "snapshot_fw.dump", "forward")
+        _num_rendered, color, alpha_integrated, color_integrated, point_coordinate, point_sdf, radii = out[:7]
+        return color, alpha_integrated, color_integrated, point_coordinate, point_sdf, radii

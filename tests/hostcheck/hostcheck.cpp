@@ -47,6 +47,22 @@ void hc_preprocess_fwd(int P, int deg, int M, const float* means, const float* s
   }
 }
 
+// INTE preprocess (integrate path): out_f [P][7] = icr0..icr5, well ; out_i [P] = radius
+void hc_preprocess_inte(int P, int deg, int M, const float* means, const float* scales, const float* rots, const float* opac,
+                        const float* shs, const float* view, const float* proj, const float* campos, int W, int H, float tanfovx,
+                        float tanfovy, float kernel_size, float scale_modifier, float* out_f, int* out_i) {
+  Camera cam = make_cam(view, proj, campos, W, H, tanfovx, tanfovy, kernel_size, scale_modifier);
+  for (int i = 0; i < P; i++) {
+    SplatFwd s;
+    memset(&s, 0, sizeof(s));
+    preprocess_fwd<true>(mk3(means[3 * i], means[3 * i + 1], means[3 * i + 2]), scales + 3 * i, rots + 4 * i, nullptr, opac[i], deg,
+                         shs + (size_t)i * M * 3, nullptr, cam, s);
+    for (int k = 0; k < 6; k++) out_f[(size_t)i * 7 + k] = s.icr[k];
+    out_f[(size_t)i * 7 + 6] = s.well ? 1.0f : 0.0f;
+    out_i[i] = s.radius;
+  }
+}
+
 // acc: [P][25] in SplatAcc field order (dcolor3,dts,drp2,dnrm3,dmean2D3,dconic3,dop,dvp3,dcp6)
 // out: [P][17] = dmean3D3,dopacity,dcov3D6,dscale3,drot4 ; dsh: [P][M][3]
 void hc_preprocess_bwd(int P, int deg, int M, const float* means, const float* scales, const float* rots, const float* cov3D_pre,

@@ -61,6 +61,19 @@ def preprocess_fwd(scene, colors=None, cov3D=None, use_sh=True):
     return out_f, out_i
 
 
+def preprocess_inte(scene):
+    s = scene
+    P = s.means3D.shape[0]
+    shs = _f(s.shs)
+    out_f = np.zeros((P, 7), np.float32)
+    out_i = np.zeros(P, np.int32)
+    lib().hc_preprocess_inte(ctypes.c_int(P), ctypes.c_int(s.sh_degree), ctypes.c_int(shs.shape[1]), _p(_f(s.means3D)), _p(_f(s.scales)),
+                             _p(_f(s.rotations)), _p(_f(s.opacities)), _p(shs), _p(_f(s.viewmatrix)), _p(_f(s.projmatrix)),
+                             _p(_f(s.campos)), ctypes.c_int(s.W), ctypes.c_int(s.H), ctypes.c_float(s.tanfovx),
+                             ctypes.c_float(s.tanfovy), ctypes.c_float(s.kernel_size), ctypes.c_float(1.0), _p(out_f), _p(out_i))
+    return out_f, out_i
+
+
 def preprocess_bwd(scene, radii, clamped, op_combined, acc, use_sh=True, cov3D=None):
     s = scene
     P = s.means3D.shape[0]

@@ -1,0 +1,125 @@
+"""GPU parity of GaussianRasterizer.integrate against the oracle: exact indices (radii, num_rendered,
+per-pixel last contributor, per-pixel point counts, projected coordinates), images / integrated opacities / sdf within
+1e-5 abs / 1e-4 rel."""
+import numpy as np
+import pytest
+import torch
+
+from synth_scene import make_scene
+from util import close, oracle_for
+
+pytestmark = pytest.mark.gpu
+
+
+def _points(s, n, seed, spread=0.05, far=0):
+    rng = np.random.default_rng(seed)
+    P = s.means3D.shape[0]
+    pts = s.means3D.numpy()[rng.integers(0, P, n)] + rng.normal(size=(n, 3)).astype(np.float32) * np.float32(spread)
+    if far:
+        pts = np.concatenate([pts, rng.normal(size=(far, 3)).astype(np.float32) * 40.0])
+    return np.ascontiguousarray(pts, dtype=np.float32)
+
+
+def _run(s, pts, debug=False):
+    import diff_gaussian_rasterization._C as C
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gpu_util import settings_for
+    from synth_scene import to_device
+    assert torch.cuda.is_available(), "these tests need the MI355X box"
+    dev = torch.device("cuda:0")
+    d = to_device(s, dev)
+    r = GaussianRasterizer(settings_for(s, dev, debug))
+    p = torch.from_numpy(pts).to(dev)
+    out = r.integrate(p, d.means3D, torch.zeros_like(d.means3D), d.opacities, shs=d.shs, scales=d.scales, rotations=d.rotations)
+    rs = r.raster_settings
+    e = torch.Tensor([])
+    st = C.integrate_gaussians_to_points(rs.bg, p, d.means3D, e, d.opacities, d.scales, d.rotations, 1.0, e, e, rs.viewmatrix,
+                                         rs.projmatrix, rs.tanfovx, rs.tanfovy, 0.0, None, s.H, s.W, d.shs, s.sh_degree, rs.campos,
+                                         False, debug)
+    torch.cuda.synchronize()
+    # the wrapper and the native entry agree, and two runs are bit-identical (no atomics on the value path)
+    for a, b in zip(out, st[1:7]):
+        assert torch.equal(a, b)
+    P = s.means3D.shape[0]
+    nc = None
+    if st[9].numel():  # the state buffers stay empty when nothing was launched (P == 0 or PN == 0)
+        nc = C.debug_export("n_contrib", torch.int32, 2 * s.H * s.W, P, st[0], s.W, s.H, False, st[7], st[8], st[9]).cpu().numpy()
+        nc = nc.view(np.uint32)
+    return st[0], [t.cpu().numpy() for t in out], nc
+
+
+def check(s, pts, min_projected=1):
+    assert s.kernel_size == 0.0  # the operator hard-codes kernel_size 0.0 for integrate (upstream __init__.py:283)
+    o = oracle_for(s)
+    ref = o.integrate(pts)
+    R, got, nc = _run(s, pts)
+    H, W = s.H, s.W
+    assert R == o.num_rendered, "num_rendered"
+    assert np.array_equal(got[5], ref[5]), "radii"
+    assert np.array_equal(nc[: H * W], o.get("n_contrib")[: H * W]), "last contributor"
+    assert np.array_equal(got[3].view(np.uint32), ref[3].view(np.uint32)), "projected coordinates (bit-exact)"
+    assert np.array_equal(got[0][8], ref[0][8]), "points per pixel"
+    proj = ref[3].any(axis=1)
+    assert proj.sum() >= min_projected
+    names = ["color9", "alpha_integrated", "color_integrated", "coordinate2d", "sdf"]
+    for k in (0, 1, 2, 4):
+        assert not np.isnan(got[k]).any(), names[k]
+        assert close(got[k], ref[k]).all(), f"{names[k]}: max abs diff {np.abs(got[k] - ref[k]).max():.3e}"
+    return o, got
+
+
+def test_integrate_random_scene():
+    s = make_scene(6000, 200, 152, sh_degree=2, mu_px=4.0, seed=31, kernel_size=0.0, pose="random", require_coord=False, require_depth=True)
+    o, got = check(s, _points(s, 20000, 1, far=500), min_projected=5000)
+    a = got[1]
+    assert ((a >= 0) & (a <= 1)).all() and (a < 0.5).sum() > 100 and (a > 0.9).sum() > 100
+
+
+def test_integrate_many_points_per_pixel_and_heavy_overdraw():
+    # 64x48 image, 30k points -> ~10 per pixel: several 4-point passes per lane; large splats -> long tile lists
+    s = make_scene(1500, 64, 48, sh_degree=0, mu_px=12.0, seed=32, kernel_size=0.0, pose="random", require_coord=False,
+                   require_depth=True, low_opacity=True)
+    o, got = check(s, _points(s, 30000, 2, spread=0.3), min_projected=10000)
+    assert got[0][8].max() > 8
+
+
+def test_integrate_ill_conditioned_gaussians():
+    from test_hostcheck import _flat_scene
+    s = _flat_scene(make_scene(3000, 160, 120, sh_degree=1, mu_px=3.0, seed=33, kernel_size=0.0, pose="random", require_coord=False,
+                               require_depth=True), frac=0.4, seed=4)
+    o, got = check(s, _points(s, 15000, 3), min_projected=3000)
+    assert (o.get("condition")[o.get("radii") > 0] == 0).sum() > 100
+
+
+def test_integrate_partial_tiles_and_identity_pose():
+    s = make_scene(2000, 100, 70, sh_degree=3, mu_px=2.0, seed=34, kernel_size=0.0, pose="identity", require_coord=False, require_depth=True)
+    check(s, _points(s, 8000, 4, far=100), min_projected=2000)
+
+
+def test_integrate_empty_inputs():
+    s = make_scene(500, 64, 48, sh_degree=0, mu_px=3.0, seed=35, kernel_size=0.0, require_coord=False, require_depth=True)
+    pts = _points(s, 100, 5)
+    # no points: image stays zero (the reference returns before launching anything, rasterize_points.cu:330)
+    R, got, _ = _run(s, pts[:0])
+    assert R == 0 and (got[0] == 0).all() and got[1].shape == (0,)
+    # no Gaussians: initial point values
+    s0 = s._replace(means3D=s.means3D[:0], opacities=s.opacities[:0], scales=s.scales[:0], rotations=s.rotations[:0], shs=s.shs[:0])
+    R, got, _ = _run(s0, pts)
+    assert R == 0 and (got[0] == 0).all() and (got[1] == 1).all() and (got[4] == -1000).all() and (got[2] == 0).all()
+    # all points behind the camera / outside the image
+    far = np.float32(-1.0) * np.abs(pts) - np.float32(50.0)
+    o = oracle_for(s)
+    ref = o.integrate(far)
+    R, got, _ = _run(s, far)
+    assert R == o.num_rendered and (got[1] == 1).all() and (got[4] == -1000).all()
+    assert close(got[0], ref[0]).all()
+
+
+def test_integrate_debug_mode_and_determinism():
+    s = make_scene(3000, 128, 96, sh_degree=1, mu_px=4.0, seed=36, kernel_size=0.0, pose="random", require_coord=False, require_depth=True)
+    pts = _points(s, 10000, 6)
+    R1, a, _ = _run(s, pts, debug=True)
+    R2, b, _ = _run(s, pts)
+    assert R1 == R2
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)

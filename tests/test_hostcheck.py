@@ -75,6 +75,27 @@ def test_preprocess_forward_and_backward_bit_exact(case):
         assert np.array_equal(bits(a), bits(b)), k
 
 
+@pytest.mark.parametrize("flat", [False, True])
+def test_integrate_preprocess_bit_exact(flat):
+    """INTE branch of computeCov2D (forward.cu:187-235): inverse ray-space covariance + conditioning flag."""
+    s = make_scene(3000, 200, 120, sh_degree=1, mu_px=3.0, seed=21, kernel_size=0.0, pose="random", require_coord=False, require_depth=True)
+    if flat:
+        s = _flat_scene(s, frac=0.5, seed=3)
+    P = s.means3D.shape[0]
+    o = oracle_for(s)
+    o.integrate(s.means3D.numpy()[:10])
+    f, r = hc.preprocess_inte(s)
+    radii = o.get("radii")
+    assert np.array_equal(radii, r)
+    vis = radii > 0
+    cond = o.get("condition")
+    assert np.array_equal(cond[vis], f[vis, 6].astype(np.uint8))
+    if flat:
+        assert (cond[vis] == 0).sum() > 100
+    icr = o.get("invraycov", (P, 6))
+    assert np.array_equal(bits(icr[vis]), bits(f[vis, :6]))
+
+
 def test_precomputed_covariance_and_colors_bit_exact():
     s = make_scene(4000, 160, 120, sh_degree=0, mu_px=2.0, seed=5, kernel_size=0.1, pose="random", require_coord=True, require_depth=True)
     P = s.means3D.shape[0]
