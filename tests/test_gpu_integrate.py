@@ -123,3 +123,16 @@ def test_integrate_debug_mode_and_determinism():
     assert R1 == R2
     for x, y in zip(a, b):
         assert np.array_equal(x, y, equal_nan=True)
+
+
+def test_integrate_C2_full_size():
+    """The benchmark scene (1M Gaussians, 1920x1080) with 2M query points scattered around the Gaussians."""
+    from synth_scene import make_config
+    s = make_config("C2", kernel_size=0.0)
+    P = s.means3D.shape[0]
+    rng = np.random.default_rng(7)
+    pts = s.means3D.numpy()[:, None, :] + rng.normal(size=(P, 2, 3)).astype(np.float32) * 1.5 * s.scales.numpy().max(1)[:, None, None]
+    o, got = check(s, np.ascontiguousarray(pts.reshape(-1, 3), dtype=np.float32), min_projected=1_000_000)
+    # size-independent properties: every projected point is counted once; integrated opacity never exceeds 1
+    assert got[0][8].sum() == (got[3].any(axis=1)).sum()
+    assert (got[1] <= 1.0 + 1e-6).all() and (got[1] >= 0).all()
