@@ -193,6 +193,49 @@ int radegs_profile_collect(float* ms_total, int* count, int n);
 const char* radegs_last_error(void);
 const char* radegs_version(void);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * The step that follows the rasterizer in every regularised training iteration: two depth (or
+ * coordinate) maps -> two normal maps by central differences, and the normal-consistency loss against the rendered
+ * normal map.  Replaces, with one kernel per direction, the torch-eager
+ *     depths_double_to_points / point_double_to_normal / depth_double_to_normal   utils/graphics_utils.py:97-127
+ *     normal_error_map / depth_normal_loss                                        train.py:152-155
+ * and their autograd backward.  All maps are float32 device pointers; normal maps are [2,3,H,W] (map 1 first).
+ * --------------------------------------------------------------------------------------------------------------- */
+typedef struct RadegsNormalArgs {
+  int width, height;
+  int points;          /* 0: map1/map2 are depth maps [1,H,W] (depth_double_to_normal); 1: coordinate maps [3,H,W] */
+  double fovx, fovy;   /* view.FoVx / view.FoVy in radians (used for depth maps only) */
+  const float* map1;   /* expected depth / expected coord */
+  const float* map2;   /* median depth / median coord */
+} RadegsNormalArgs;
+
+int radegs_normals_forward(const RadegsNormalArgs* args, float* out_normals /* [2,3,H,W] */, void* stream);
+/* grad_map1/2 have the shape of map1/2; every element is written */
+int radegs_normals_backward(const RadegsNormalArgs* args, const float* grad_normals /* [2,3,H,W] */, float* grad_map1, float* grad_map2,
+                            void* stream);
+/* loss = (1-depth_ratio) * mean(1 - n.N_1) + depth_ratio * mean(1 - n.N_2), means over all H*W pixels (border: N = 0).
+ * out_loss3 = {loss, mean error map 1, mean error map 2}; scratch: radegs_normal_loss_scratch_bytes() bytes. */
+size_t radegs_normal_loss_scratch_bytes(int width, int height);
+int radegs_normal_loss_forward(const RadegsNormalArgs* args, const float* rendered_normal /* [3,H,W] */, float depth_ratio, void* scratch,
+                               float* out_loss3, void* stream);
+/* upstream: device scalar d(objective)/d(loss) or NULL (= 1) */
+int radegs_normal_loss_backward(const RadegsNormalArgs* args, const float* rendered_normal, float depth_ratio, const float* upstream,
+                                float* grad_map1, float* grad_map2, float* grad_rendered_normal /* [3,H,W] */, void* stream);
+const char* radegs_normals_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * The step that precedes the rasterizer in every render() call: parameter activations fused with
+ * the 3D (mip) filter -- GaussianModel.get_scaling_n_opacity_with_3D_filter, scene/gaussian_model.py:156-166.
+ *   scales[P,3] = sqrt(exp(scaling_raw)^2 + filter_3D^2);  opacity[P] = sigmoid(opacity_raw) * sqrt(det1/det2)
+ * backward: grad_scales / grad_opacity may be NULL (= zero cotangent); filter_3D carries no gradient upstream either.
+ * --------------------------------------------------------------------------------------------------------------- */
+int radegs_filter3d_forward(int P, const float* scaling_raw /* [P,3] */, const float* opacity_raw /* [P,1] */,
+                            const float* filter_3D /* [P,1] */, float* scales_out /* [P,3] */, float* opacity_out /* [P,1] */,
+                            void* stream);
+int radegs_filter3d_backward(int P, const float* scaling_raw, const float* opacity_raw, const float* filter_3D, const float* grad_scales,
+                             const float* grad_opacity, float* grad_scaling_raw /* [P,3] */, float* grad_opacity_raw /* [P,1] */,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

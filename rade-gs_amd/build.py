@@ -26,7 +26,11 @@ UNITS = {
     "radegs_sort": ["radegs_sort.hip", "rg_prims.h"],
     "radegs_kernels": ["radegs_kernels.hip", "rg_launch.inc", "rg_math.h", "rg_blend.h", "rg_preprocess.h", "rg_preprocess_bwd.h",
                        "rg_layout.h", "rg_prims.h", os.path.join("..", "..", "include", "radegs.h")],
+    "radegs_normals": ["radegs_normals.hip", os.path.join("..", "..", "include", "radegs.h")],
+    "radegs_filter3d": ["radegs_filter3d.hip", os.path.join("..", "..", "include", "radegs.h")],
 }
+# Units outside the rasterizer's decision chain have no bit-exactness contract with the oracle: let them contract to fma.
+UNIT_FLAGS = {"radegs_normals": ["-ffp-contract=fast"], "radegs_filter3d": ["-ffp-contract=fast"]}
 
 
 def _stale(target, deps):
@@ -44,7 +48,7 @@ def build(force=False, verbose=True):
         deps = [os.path.join(CSRC, f) for f in files] + [os.path.abspath(__file__)]
         obj = os.path.join(OBJ_DIR, name + ".o")
         if force or _stale(obj, deps):
-            cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, files[0]), "-o", obj]
+            cmd = [hipcc] + FLAGS + UNIT_FLAGS.get(name, []) + ["-c", os.path.join(CSRC, files[0]), "-o", obj]
             if verbose:
                 print("[radegs build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -74,7 +74,11 @@ class RadegsIntegrateArgs(ctypes.Structure):
 # every symbol include/radegs.h declares
 EXPORTED_SYMBOLS = ("radegs_forward", "radegs_backward", "radegs_mark_visible", "radegs_integrate", "radegs_geometry_bytes", "radegs_image_bytes",
                     "radegs_binning_bytes", "radegs_debug_export", "radegs_last_error", "radegs_version", "radegs_profile_enable",
-                    "radegs_profile_num_stages", "radegs_profile_stage_name", "radegs_profile_collect")
+                    "radegs_profile_num_stages", "radegs_profile_stage_name", "radegs_profile_collect",
+                    # fused pre/post steps (bound in graphics_utils.py / gaussian_model_ops.py)
+                    "radegs_normals_forward", "radegs_normals_backward", "radegs_normal_loss_scratch_bytes",
+                    "radegs_normal_loss_forward", "radegs_normal_loss_backward", "radegs_normals_last_error",
+                    "radegs_filter3d_forward", "radegs_filter3d_backward")
 
 _lib = None
 # test hook: when True, the per-Gaussian accumulation scratch of the last backward is kept in LAST_ACC

@@ -1,0 +1,90 @@
+"""Times the fused pre/post steps against the same math written as eager torch ops the way the
+reference does (utils/graphics_utils.py:97-127 + train.py:152-155; scene/gaussian_model.py:156-166).  GPU box only."""
+import math, os, sys, time
+from collections import namedtuple
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("", "rade-gs_amd"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+import torch
+import graphics_utils as gu
+import gaussian_model_ops as gmo
+
+dev = torch.device("cuda:0")
+View = namedtuple("View", "image_width image_height FoVx FoVy")
+W, H = 1920, 1080
+view = View(W, H, 1.0, 2 * math.atan(math.tan(0.5) * H / W))
+
+
+def timeit(fn, n=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+# ---- eager restatement of the reference step (timing baseline only) ----
+def eager_depth_double_to_normal(view, d1, d2):
+    fx = W / (2 * math.tan(view.FoVx / 2.)); fy = H / (2 * math.tan(view.FoVy / 2.))
+    k = torch.tensor([[1 / fx, 0., -W / (2 * fx)], [0., 1 / fy, -H / (2 * fy)], [0., 0., 1.0]]).float().to(dev)
+    gx, gy = torch.meshgrid(torch.arange(W) + 0.5, torch.arange(H) + 0.5, indexing='xy')
+    pts = torch.stack([gx, gy, torch.ones_like(gx)], dim=0).reshape(3, -1).float().to(dev)
+    rays = k @ pts
+    p = torch.stack([(d1.reshape(1, -1) * rays).reshape(3, H, W), (d2.reshape(1, -1) * rays).reshape(3, H, W)], dim=0)
+    out = torch.zeros_like(p)
+    dx = p[..., 2:, 1:-1] - p[..., :-2, 1:-1]
+    dy = p[..., 1:-1, 2:] - p[..., 1:-1, :-2]
+    out[..., 1:-1, 1:-1] = torch.nn.functional.normalize(torch.cross(dx, dy, dim=1), dim=1)
+    return out
+
+
+d1 = (4 + torch.rand(1, H, W, device=dev)).requires_grad_(True)
+d2 = (4 + torch.rand(1, H, W, device=dev)).requires_grad_(True)
+rn = torch.nn.functional.normalize(torch.randn(3, H, W, device=dev), dim=0).requires_grad_(True)
+
+
+def eager_step():
+    nm = eager_depth_double_to_normal(view, d1, d2)
+    err = 1 - (rn.unsqueeze(0) * nm).sum(dim=1)
+    loss = 0.4 * err[0].mean() + 0.6 * err[1].mean()
+    loss.backward()
+
+
+def fused_step():
+    gu.normal_consistency_loss(view, rn, d1, d2, 0.6).backward()
+
+
+te, tf = timeit(eager_step), timeit(fused_step)
+# algorithmic bytes: fwd reads 2 depth + 3 normal maps (20 B/px); bwd reads them again and writes 2 + 3 maps (40 B/px)
+gb = 60.0 * W * H / 1e9
+print(f"normal-consistency loss fwd+bwd @1080p: eager torch {te:.3f} ms, fused HIP {tf:.3f} ms ({te/tf:.1f}x); "
+      f"fused = {gb / (tf * 1e-3):.0f} GB/s algorithmic incl. autograd/launch overhead")
+
+P = 1_000_000
+sc = (torch.randn(P, 3, device=dev) - 4.6).requires_grad_(True)
+op = torch.randn(P, 1, device=dev).requires_grad_(True)
+f3 = 0.001 + 0.02 * torch.rand(P, 1, device=dev)
+
+
+def eager_filter():
+    opacity = torch.sigmoid(op)
+    scales = torch.exp(sc)
+    s2 = torch.square(scales)
+    det1 = s2.prod(dim=1)
+    a2 = s2 + torch.square(f3)
+    det2 = a2.prod(dim=1)
+    coef = torch.sqrt(det1 / det2)
+    s, o = torch.sqrt(a2), opacity * coef[..., None]
+    (s.sum() + o.sum()).backward()
+
+
+def fused_filter():
+    s, o = gmo.scaling_n_opacity_with_3D_filter(sc, op, f3)
+    (s.sum() + o.sum()).backward()
+
+
+te, tf = timeit(eager_filter), timeit(fused_filter)
+print(f"3D filter + activations fwd+bwd, P=1M: eager torch {te:.3f} ms, fused HIP {tf:.3f} ms ({te/tf:.1f}x)")

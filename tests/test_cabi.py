@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "radegs.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(radegs_[a-z_]+)\s*\(", hdr)) - {"radegs_alloc_fn"})
+    return sorted(set(re.findall(r"\b(radegs_[a-z0-9_]+)\s*\(", hdr)) - {"radegs_alloc_fn"})
 
 
 def test_header_symbols_are_exported():
@@ -76,3 +76,18 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle|#include\s+\"[^\"]*oracle|liboracle", txt, flags=re.M):
                     bad.append(f)
     assert not bad, bad
+
+
+def test_fused_step_modules_have_no_cpu_fallback():
+    """graphics_utils / gaussian_model_ops refuse CPU tensors instead of falling back."""
+    from collections import namedtuple
+    import gaussian_model_ops as gmo
+    import graphics_utils as gu
+    View = namedtuple("View", "image_width image_height FoVx FoVy")
+    v = View(8, 8, 1.0, 1.0)
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        gu.depth_double_to_normal(v, torch.ones(1, 8, 8), torch.ones(1, 8, 8))
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        gu.normal_consistency_loss(v, torch.ones(3, 8, 8), torch.ones(1, 8, 8), torch.ones(1, 8, 8))
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        gmo.scaling_n_opacity_with_3D_filter(torch.zeros(4, 3), torch.zeros(4, 1), torch.zeros(4, 1))

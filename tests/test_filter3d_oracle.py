@@ -1,0 +1,24 @@
+"""oracle/filter3d_oracle.py against the golden vectors produced by the REFERENCE's GaussianModel property
+(tests/golden/make_golden_filter3d.py): this oracle row is PINNED to the reference."""
+import os
+
+import numpy as np
+
+from oracle import filter3d_oracle as fo
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "filter3d.npz"))
+
+
+def test_forward_matches_reference():
+    for dt, tol in ((np.float32, 2e-6), (np.float64, 1e-6)):
+        s, o = fo.forward(G["scaling_raw"].astype(dt), G["opacity_raw"].astype(dt), G["filter_3D"].astype(dt))
+        assert np.allclose(s, G["scales"], rtol=tol, atol=1e-12)
+        assert np.allclose(o, G["opacity"], rtol=10 * tol, atol=1e-9)
+
+
+def test_backward_matches_reference_autograd():
+    a = [G[k].astype(np.float64) for k in ("scaling_raw", "opacity_raw", "filter_3D", "cot_scales", "cot_opacity")]
+    gs, go = fo.backward(*a)
+    assert np.allclose(gs, G["g_scaling_raw"], rtol=2e-4, atol=1e-7 * np.abs(G["g_scaling_raw"]).max())
+    assert np.allclose(go, G["g_opacity_raw"], rtol=2e-4, atol=1e-7 * np.abs(G["g_opacity_raw"]).max())
+    assert np.isfinite(G["g_scaling_raw"]).all()

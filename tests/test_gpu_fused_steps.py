@@ -1,0 +1,147 @@
+"""GPU parity of the fused pre/post steps against (a) the golden vectors produced by the reference's
+own Python on the CPU (tests/golden/normals_*.npz, filter3d.npz) and (b) the numpy oracles at larger sizes.
+Tolerance: 1e-5 abs / 1e-4 rel on values; gradients of normalize(cross(.)) are compared at the fp32 noise level of the
+reference's own autograd (the golden gradients are fp32 too)."""
+import os
+from collections import namedtuple
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import filter3d_oracle as fo
+from oracle import normal_oracle as no
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+View = namedtuple("View", "image_width image_height FoVx FoVy")
+
+
+def _t(a, grad=False):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to("cuda:0").requires_grad_(grad)
+
+
+def _close(a, b, rtol=1e-4, atol=1e-5):
+    return np.abs(a - b) <= atol + rtol * np.abs(b)
+
+
+@pytest.mark.parametrize("name", ["depth_smooth", "depth_rough", "points"])
+def test_normals_and_loss_match_reference_golden(name):
+    import graphics_utils as gu
+    assert torch.cuda.is_available()
+    z = np.load(os.path.join(GOLD, f"normals_{name}.npz"))
+    W, H = int(z["W"]), int(z["H"])
+    view = View(W, H, float(z["fovx"]), float(z["fovy"]))
+    pts = "points1" in z.files
+    m1, m2 = (_t(z["points1"], True), _t(z["points2"], True)) if pts else (_t(z["depth1"], True), _t(z["depth2"], True))
+    rn = _t(z["rendered_normal"], True)
+    fn = gu.point_double_to_normal if pts else gu.depth_double_to_normal
+    nm = fn(view, m1, m2)
+    assert np.abs(nm.detach().cpu().numpy() - z["normals"]).max() < 2e-5
+    # un-fused: the reference's loss expression on our normal maps, autograd through the HIP backward
+    err = 1 - (rn.unsqueeze(0) * nm).sum(dim=1)
+    loss = 0.4 * err[0].mean() + 0.6 * err[1].mean()
+    loss.backward()
+    assert abs(loss.item() - float(z["loss"])) < 2e-6
+    grads_unfused = [t.grad.detach().cpu().numpy().copy() for t in (m1, m2, rn)]
+    for t in (m1, m2, rn):
+        t.grad = None
+    # fused
+    lf = gu.normal_consistency_loss(view, rn, m1, m2, 0.6, points=pts)
+    lf.backward()
+    assert abs(lf.item() - float(z["loss"])) < 2e-6
+    grads_fused = [t.grad.detach().cpu().numpy() for t in (m1, m2, rn)]
+    for got in (grads_unfused, grads_fused):
+        for a, k in zip(got, ("g1", "g2", "g_rendered")):
+            ref = z[k].reshape(a.shape)
+            scale = np.abs(ref).max()
+            assert np.abs(a - ref).max() < 2e-3 * scale, (k, np.abs(a - ref).max(), scale)
+            assert np.median(np.abs(a - ref)) < 1e-5 * scale, k
+    # generic cotangent
+    for t in (m1, m2):
+        t.grad = None
+    (fn(view, m1, m2) * _t(z["cot"])).sum().backward()
+    for t, k in ((m1, "c1"), (m2, "c2")):
+        ref = z[k].reshape(t.shape)
+        a = t.grad.cpu().numpy()
+        assert np.abs(a - ref).max() < 2e-3 * np.abs(ref).max() and np.median(np.abs(a - ref)) < 1e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("points", [False, True])
+def test_normal_loss_full_hd_against_oracle(points):
+    import graphics_utils as gu
+    W, H = 1920, 1080
+    rng = np.random.default_rng(5)
+    fovx = 1.0
+    fovy = 2 * np.arctan(np.tan(fovx / 2) * H / W)
+    view = View(W, H, fovx, fovy)
+    y, x = np.mgrid[0:H, 0:W]
+    d1 = (4 + np.sin(x / 40.0) * np.cos(y / 25.0) + 0.01 * rng.standard_normal((H, W))).astype(np.float32)
+    d2 = (d1 + 0.03 * np.cos(x / 13.0)).astype(np.float32)
+    rn = rng.standard_normal((3, H, W)).astype(np.float32)
+    rn /= np.linalg.norm(rn, axis=0, keepdims=True)
+    if points:
+        p1, p2 = no.depths_to_points(d1, d2, W, H, fovx, fovy)
+        maps64 = np.stack([p1, p2], 0).astype(np.float64)
+        m1, m2 = _t(p1, True), _t(p2, True)
+    else:
+        q1, q2 = no.depths_to_points(d1.astype(np.float64), d2.astype(np.float64), W, H, fovx, fovy)
+        maps64 = np.stack([q1, q2], 0)
+        m1, m2 = _t(d1.reshape(1, H, W), True), _t(d2.reshape(1, H, W), True)
+    r = _t(rn, True)
+    loss = gu.normal_consistency_loss(view, r, m1, m2, 0.6, points=points)
+    (loss * 3.0).backward()          # non-unit upstream gradient
+    nm64, _ = no.points_to_normal(maps64)
+    ref_loss = no.consistency_loss(rn.astype(np.float64), nm64)
+    assert abs(loss.item() - ref_loss) < 1e-5
+    g_rn, g_nm = no.consistency_loss_bwd(rn.astype(np.float64), nm64, upstream=3.0)
+    # N is a normalised cross product of fp32 differences of depth ~4: abs error ~1e-5 of unit length
+    assert _close(r.grad.cpu().numpy(), g_rn, atol=1e-4 * np.abs(g_rn).max()).all()
+    gp = no.points_to_normal_bwd(maps64, g_nm)
+    if points:
+        refs = (gp[0], gp[1])
+    else:
+        ray = no.rays(W, H, fovx, fovy, np.float64)
+        refs = ((gp[0] * ray).sum(0)[None], (gp[1] * ray).sum(0)[None])
+    for t, ref in zip((m1, m2), refs):
+        a = t.grad.cpu().numpy()
+        scale = np.abs(ref).max()
+        assert np.median(np.abs(a - ref)) < 1e-5 * scale
+        assert (np.abs(a - ref) < 1e-2 * scale).mean() > 0.9999    # fp32 cancellation in (P(y+1)-P(y-1)) x (...) at a few pixels
+    # determinism (no atomics anywhere)
+    l2 = gu.normal_consistency_loss(view, r.detach(), m1.detach(), m2.detach(), 0.6, points=points)
+    assert l2.item() == loss.item()
+
+
+def test_filter3d_matches_reference_golden_and_oracle():
+    import gaussian_model_ops as gmo
+    z = np.load(os.path.join(GOLD, "filter3d.npz"))
+    sc, op, f3 = _t(z["scaling_raw"], True), _t(z["opacity_raw"], True), _t(z["filter_3D"])
+    s, o = gmo.scaling_n_opacity_with_3D_filter(sc, op, f3)
+    assert np.allclose(s.detach().cpu().numpy(), z["scales"], rtol=1e-5, atol=1e-12)
+    assert np.allclose(o.detach().cpu().numpy(), z["opacity"], rtol=1e-4, atol=1e-9)
+    ((s * _t(z["cot_scales"])).sum() + (o * _t(z["cot_opacity"])).sum()).backward()
+    for t, k in ((sc, "g_scaling_raw"), (op, "g_opacity_raw")):
+        ref = z[k]
+        assert np.allclose(t.grad.cpu().numpy(), ref, rtol=3e-4, atol=1e-6 * np.abs(ref).max()), k
+    # 1M Gaussians against the float64 oracle
+    rng = np.random.default_rng(1)
+    P = 1_000_000
+    a = (np.log(0.01) + rng.standard_normal((P, 3))).astype(np.float32)
+    b = (2 * rng.standard_normal((P, 1))).astype(np.float32)
+    c = (0.001 + 0.02 * rng.random((P, 1))).astype(np.float32)
+    cs, co = rng.standard_normal((P, 3)).astype(np.float32), rng.standard_normal((P, 1)).astype(np.float32)
+    ta, tb = _t(a, True), _t(b, True)
+    s, o = gmo.scaling_n_opacity_with_3D_filter(ta, tb, _t(c))
+    rs, ro = fo.forward(a.astype(np.float64), b.astype(np.float64), c.astype(np.float64))
+    assert np.allclose(s.detach().cpu().numpy(), rs, rtol=1e-5) and np.allclose(o.detach().cpu().numpy(), ro, rtol=1e-4, atol=1e-9)
+    ((s * _t(cs)).sum() + (o * _t(co)).sum()).backward()
+    gs, go = fo.backward(a.astype(np.float64), b.astype(np.float64), c.astype(np.float64), cs.astype(np.float64), co.astype(np.float64))
+    assert np.allclose(ta.grad.cpu().numpy(), gs, rtol=1e-4, atol=1e-6 * np.abs(gs).max())
+    assert np.allclose(tb.grad.cpu().numpy(), go, rtol=1e-4, atol=1e-6 * np.abs(go).max())
+    # only one cotangent present (the other output unused downstream)
+    ta.grad = None
+    s, o = gmo.scaling_n_opacity_with_3D_filter(ta, tb, _t(c))
+    s.sum().backward()
+    gs1, _ = fo.backward(a.astype(np.float64), b.astype(np.float64), c.astype(np.float64), np.ones_like(cs, dtype=np.float64), np.zeros((P, 1)))
+    assert np.allclose(ta.grad.cpu().numpy(), gs1, rtol=1e-4, atol=1e-6 * np.abs(gs1).max())
