@@ -236,6 +236,20 @@ int radegs_filter3d_backward(int P, const float* scaling_raw, const float* opaci
                              const float* grad_opacity, float* grad_scaling_raw /* [P,3] */, float* grad_opacity_raw /* [P,1] */,
                              void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * The photometric loss that closes every training iteration:
+ *     (1 - lambda) * l1_loss(image, gt) + lambda * (1 - ssim(image, gt))      train.py:159, utils/loss_utils.py:17-63
+ * image / gt: [C,H,W] float32.  forward writes out_loss3 = {loss, l1, ssim}; when `dmaps` ([3,C,H,W]) is given it also
+ * stores the per-pixel SSIM derivative maps the backward consumes.  backward: grad_image = coef2[0] * d l1/d image +
+ * coef2[1] * d ssim/d image (coef2: two DEVICE floats, e.g. {g*(1-lambda), -g*lambda} for upstream gradient g).
+ * --------------------------------------------------------------------------------------------------------------- */
+size_t radegs_photometric_scratch_bytes(int width, int height, int channels);
+int radegs_photometric_forward(int width, int height, int channels, const float* image, const float* gt, float lambda_dssim, void* scratch,
+                               float* dmaps, float* out_loss3, void* stream);
+int radegs_photometric_backward(int width, int height, int channels, const float* image, const float* gt, const float* dmaps,
+                                const float* coef2, float* grad_image, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,9 +28,11 @@ UNITS = {
                        "rg_layout.h", "rg_prims.h", os.path.join("..", "..", "include", "radegs.h")],
     "radegs_normals": ["radegs_normals.hip", os.path.join("..", "..", "include", "radegs.h")],
     "radegs_filter3d": ["radegs_filter3d.hip", os.path.join("..", "..", "include", "radegs.h")],
+    "radegs_photometric": ["radegs_photometric.hip", os.path.join("..", "..", "include", "radegs.h")],
 }
 # Units outside the rasterizer's decision chain have no bit-exactness contract with the oracle: let them contract to fma.
-UNIT_FLAGS = {"radegs_normals": ["-ffp-contract=fast"], "radegs_filter3d": ["-ffp-contract=fast"]}
+UNIT_FLAGS = {"radegs_normals": ["-ffp-contract=fast"], "radegs_filter3d": ["-ffp-contract=fast"],
+              "radegs_photometric": ["-ffp-contract=fast"]}
 
 
 def _stale(target, deps):

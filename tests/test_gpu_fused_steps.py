@@ -145,3 +145,40 @@ def test_filter3d_matches_reference_golden_and_oracle():
     s.sum().backward()
     gs1, _ = fo.backward(a.astype(np.float64), b.astype(np.float64), c.astype(np.float64), np.ones_like(cs, dtype=np.float64), np.zeros((P, 1)))
     assert np.allclose(ta.grad.cpu().numpy(), gs1, rtol=1e-4, atol=1e-6 * np.abs(gs1).max())
+
+
+@pytest.mark.parametrize("name", ["small", "wide"])
+def test_photometric_loss_matches_reference_golden(name):
+    import loss_utils as lu
+    from oracle import loss_oracle as lo
+    z = np.load(os.path.join(GOLD, f"losses_{name}.npz"))
+    img, gt = _t(z["img"], True), _t(z["gt"])
+    loss = lu.photometric_loss(img, gt.unsqueeze(0), 0.2)       # gt with the batch dimension train.py adds
+    loss.backward()
+    assert abs(loss.item() - float(z["loss"])) < 2e-6
+    ref = z["grad"]
+    assert np.abs(img.grad.cpu().numpy() - ref).max() < 1e-4 * np.abs(ref).max()
+    # the un-fused names
+    assert abs(lu.l1_loss(img.detach(), gt).item() - float(z["l1"])) < 1e-6
+    assert abs(lu.ssim(img.detach(), gt).item() - float(z["ssim"])) < 5e-6
+    # composing the two separately gives the same gradient as the fused call
+    img.grad = None
+    (0.8 * lu.l1_loss(img, gt) + 0.2 * (1.0 - lu.ssim(img, gt))).backward()
+    assert np.abs(img.grad.cpu().numpy() - ref).max() < 1e-4 * np.abs(ref).max()
+
+
+def test_photometric_loss_full_hd_against_oracle():
+    import loss_utils as lu
+    from oracle import loss_oracle as lo
+    H, W = 1080, 1920
+    rng = np.random.default_rng(9)
+    y, x = np.mgrid[0:H, 0:W]
+    gt = np.stack([0.5 + 0.4 * np.sin(x / 9.0 + c) * np.cos(y / 7.0 - c) for c in range(3)], 0).astype(np.float32)
+    img = np.clip(gt + 0.1 * rng.standard_normal((3, H, W)), 0, 1).astype(np.float32)
+    a = _t(img, True)
+    loss = lu.photometric_loss(a, _t(gt), 0.2)
+    (2.0 * loss).backward()
+    assert abs(loss.item() - lo.rgb_loss(img.astype(np.float64), gt.astype(np.float64), 0.2)) < 2e-6
+    ref = lo.rgb_loss_bwd(img.astype(np.float64), gt.astype(np.float64), 0.2, upstream=2.0)
+    assert np.abs(a.grad.cpu().numpy() - ref).max() < 1e-4 * np.abs(ref).max()
+    assert lu.photometric_loss(a.detach(), _t(gt), 0.2).item() == loss.item()     # deterministic
