@@ -250,6 +250,23 @@ int radegs_photometric_forward(int width, int height, int channels, const float*
 int radegs_photometric_backward(int width, int height, int channels, const float* image, const float* gt, const float* dmaps,
                                 const float* coef2, float* grad_image, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Multi-tensor Adam step: torch.optim.Adam(l, lr=0.0, eps=1e-15) of scene/gaussian_model.py:338-349
+ * (no weight decay, no amsgrad) over up to RADEGS_ADAM_MAX_TENSORS parameter tensors in one launch.  `step` is the
+ * step count AFTER this update (>= 1); `lr` the group's current learning rate.  All pointers: float32, device.
+ * --------------------------------------------------------------------------------------------------------------- */
+#define RADEGS_ADAM_MAX_TENSORS 16
+typedef struct RadegsAdamTensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  unsigned long long numel;
+  float lr;
+  double step;
+} RadegsAdamTensor;
+int radegs_adam_step(int count, const RadegsAdamTensor* tensors, double beta1, double beta2, double eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,7 +79,7 @@ EXPORTED_SYMBOLS = ("radegs_forward", "radegs_backward", "radegs_mark_visible", 
                     "radegs_normals_forward", "radegs_normals_backward", "radegs_normal_loss_scratch_bytes",
                     "radegs_normal_loss_forward", "radegs_normal_loss_backward", "radegs_normals_last_error",
                     "radegs_filter3d_forward", "radegs_filter3d_backward", "radegs_photometric_scratch_bytes",
-                    "radegs_photometric_forward", "radegs_photometric_backward")
+                    "radegs_photometric_forward", "radegs_photometric_backward", "radegs_adam_step")
 
 _lib = None
 # test hook: when True, the per-Gaussian accumulation scratch of the last backward is kept in LAST_ACC

@@ -182,3 +182,59 @@ def test_photometric_loss_full_hd_against_oracle():
     ref = lo.rgb_loss_bwd(img.astype(np.float64), gt.astype(np.float64), 0.2, upstream=2.0)
     assert np.abs(a.grad.cpu().numpy() - ref).max() < 1e-4 * np.abs(ref).max()
     assert lu.photometric_loss(a.detach(), _t(gt), 0.2).item() == loss.item()     # deterministic
+
+
+def test_fused_adam_matches_torch_golden_and_survives_state_surgery():
+    import fused_adam
+    from oracle import adam_oracle as ao
+    z = np.load(os.path.join(GOLD, "adam.npz"))
+    lrs = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 2.5e-3 / 20, "opacity": 0.05, "scaling": 0.005, "rotation": 0.001}
+    params = {k: torch.nn.Parameter(_t(z[f"p0_{k}"])) for k in lrs}
+    opt = fused_adam.Adam([{"params": [params[k]], "lr": lrs[k], "name": k} for k in lrs], lr=0.0, eps=1e-15)
+    for it in range(3):
+        for k, p in params.items():
+            p.grad = _t(z[f"g{it}_{k}"])
+        if it == 2:
+            opt.param_groups[0]["lr"] = 1.0e-4
+        opt.step()
+        for k, p in params.items():
+            ref = z[f"p{it + 1}_{k}"]
+            assert np.abs(p.detach().cpu().numpy() - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()) + 2e-7, (k, it)
+    for k, p in params.items():
+        st = opt.state[p]
+        assert float(st["step"]) == 3.0
+        assert np.allclose(st["exp_avg"].cpu().numpy(), z[f"m_{k}"], rtol=1e-5, atol=1e-12)
+        assert np.allclose(st["exp_avg_sq"].cpu().numpy(), z[f"v_{k}"], rtol=1e-5, atol=1e-20)
+    # the reference's cat_tensors_to_optimizer surgery (scene/gaussian_model.py:615-633) on our optimizer, then one more step
+    g = opt.param_groups[3]
+    old = g["params"][0]
+    ext = torch.zeros(7, 1, device="cuda:0")
+    st = opt.state.get(old)
+    st["exp_avg"] = torch.cat((st["exp_avg"], torch.zeros_like(ext)), dim=0)
+    st["exp_avg_sq"] = torch.cat((st["exp_avg_sq"], torch.zeros_like(ext)), dim=0)
+    del opt.state[old]
+    g["params"][0] = torch.nn.Parameter(torch.cat((old.detach(), ext), dim=0).requires_grad_(True))
+    opt.state[g["params"][0]] = st
+    newp = g["params"][0]
+    before = newp.detach().cpu().numpy().copy()
+    grad = np.random.default_rng(3).standard_normal((1007, 1)).astype(np.float32)
+    newp.grad = _t(grad)
+    m0, v0 = st["exp_avg"].cpu().numpy().copy(), st["exp_avg_sq"].cpu().numpy().copy()
+    for k, p in params.items():
+        p.grad = None
+    opt.step()
+    ref, _, _ = ao.step(before, grad, m0, v0, 4, 0.05)
+    assert np.abs(newp.detach().cpu().numpy() - ref).max() < 1e-6
+    # odd sizes / unaligned tails / 1M x 59 floats against the oracle
+    rng = np.random.default_rng(4)
+    shapes = [(1_000_003, 3), (1_000_003, 15, 3), (5,), (1_000_003, 1)]
+    ps = [torch.nn.Parameter(_t(rng.standard_normal(s))) for s in shapes]
+    opt = fused_adam.Adam([{"params": [p], "lr": 1e-3 * (i + 1)} for i, p in enumerate(ps)], lr=0.0, eps=1e-15)
+    gs = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+    p0 = [p.detach().cpu().numpy().copy() for p in ps]
+    for p, g_ in zip(ps, gs):
+        p.grad = _t(g_)
+    opt.step()
+    for i, (p, g_, q) in enumerate(zip(ps, gs, p0)):
+        ref, _, _ = ao.step(q, g_, np.zeros_like(q), np.zeros_like(q), 1, 1e-3 * (i + 1))
+        assert np.abs(p.detach().cpu().numpy() - ref).max() < 1e-6
