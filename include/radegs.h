@@ -235,6 +235,12 @@ int radegs_filter3d_forward(int P, const float* scaling_raw /* [P,3] */, const f
 int radegs_filter3d_backward(int P, const float* scaling_raw, const float* opacity_raw, const float* filter_3D, const float* grad_scales,
                              const float* grad_opacity, float* grad_scaling_raw /* [P,3] */, float* grad_opacity_raw /* [P,1] */,
                              void* stream);
+/* GaussianModel.compute_3D_filter (scene/gaussian_model.py:179-232) over all cameras in one pass.  cameras16: [ncam][16]
+ * device floats = R (3x3 row-major as stored: p_cam = p @ R + T), T (3), focal_x, focal_y, width, height.
+ * focal_length: max focal_x over the cameras (host).  scratch_distance: [P] floats, scratch_max: 1 uint32 (device).
+ * filter_3D[P] = min-depth / focal_length * sqrt(0.2); Gaussians no camera sees get the largest valid depth. */
+int radegs_compute_filter3d(int P, const float* xyz, int ncam, const float* cameras16, float focal_length, float* scratch_distance,
+                            unsigned* scratch_max, float* filter_3D, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------------------------

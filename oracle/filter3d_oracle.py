@@ -25,3 +25,27 @@ def backward(scaling_raw, opacity_raw, filter_3D, g_scales, g_opacity):
     g_op_raw = g_opacity * coef * sg * (1 - sg)
     g_sc_raw = g_scales * s2 / np.sqrt(a2) + (g_opacity * sg * coef) * f2 / a2
     return g_sc_raw, g_op_raw
+
+
+def compute_3D_filter(xyz, cameras):
+    """scene/gaussian_model.py:179-232 in numpy float32.  cameras: objects with R, T, image_width, image_height, FoVx, FoVy."""
+    import math
+    xyz = xyz.astype(np.float32)
+    distance = np.full(xyz.shape[0], 100000.0, dtype=np.float32)
+    valid_points = np.zeros(xyz.shape[0], dtype=bool)
+    focal_length = 0.0
+    for cam in cameras:
+        W, H = cam.image_width, cam.image_height
+        fx, fy = W / (2 * math.tan(cam.FoVx / 2.)), H / (2 * math.tan(cam.FoVy / 2.))
+        pc = xyz @ np.asarray(cam.R, dtype=np.float32) + np.asarray(cam.T, dtype=np.float32)[None, :]
+        valid_depth = pc[:, 2] > 0.2
+        z = np.maximum(pc[:, 2], np.float32(0.001))
+        x = pc[:, 0] / z * np.float32(fx) + np.float32(W / 2.0)
+        y = pc[:, 1] / z * np.float32(fy) + np.float32(H / 2.0)
+        in_screen = (x >= -0.15 * W) & (x <= W * 1.15) & (y >= -0.15 * H) & (y <= 1.15 * H)
+        valid = valid_depth & in_screen
+        distance[valid] = np.minimum(distance[valid], z[valid])
+        valid_points |= valid
+        focal_length = max(focal_length, fx)
+    distance[~valid_points] = distance[valid_points].max()
+    return (distance / np.float32(focal_length) * np.float32(0.2 ** 0.5))[:, None]

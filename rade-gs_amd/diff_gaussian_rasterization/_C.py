@@ -78,7 +78,8 @@ EXPORTED_SYMBOLS = ("radegs_forward", "radegs_backward", "radegs_mark_visible", 
                     # fused pre/post steps (bound in graphics_utils.py / gaussian_model_ops.py)
                     "radegs_normals_forward", "radegs_normals_backward", "radegs_normal_loss_scratch_bytes",
                     "radegs_normal_loss_forward", "radegs_normal_loss_backward", "radegs_normals_last_error",
-                    "radegs_filter3d_forward", "radegs_filter3d_backward", "radegs_photometric_scratch_bytes",
+                    "radegs_filter3d_forward", "radegs_filter3d_backward", "radegs_compute_filter3d",
+                    "radegs_photometric_scratch_bytes",
                     "radegs_photometric_forward", "radegs_photometric_backward", "radegs_adam_step")
 
 _lib = None

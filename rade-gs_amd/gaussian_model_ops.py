@@ -19,6 +19,8 @@ def _lib():
         L.radegs_filter3d_forward.argtypes = [ctypes.c_int] + [vp] * 6
         L.radegs_filter3d_backward.restype = ctypes.c_int
         L.radegs_filter3d_backward.argtypes = [ctypes.c_int] + [vp] * 8
+        L.radegs_compute_filter3d.restype = ctypes.c_int
+        L.radegs_compute_filter3d.argtypes = [ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_float, vp, vp, vp, vp]
         _bound = True
     return L
 
@@ -63,3 +65,36 @@ def scaling_n_opacity_with_3D_filter(scaling_raw, opacity_raw, filter_3D):
     """(scales[P,3], opacity[P,1]) = GaussianModel.get_scaling_n_opacity_with_3D_filter evaluated on the raw parameters
     `_scaling` (log-space), `_opacity` (logit) and the `filter_3D` buffer.  Differentiable w.r.t. the two parameters."""
     return _ScalingOpacity3DFilter.apply(scaling_raw, opacity_raw, filter_3D)
+
+
+@torch.no_grad()
+def compute_3D_filter(xyz, cameras):
+    """GaussianModel.compute_3D_filter (scene/gaussian_model.py:179-232): returns the (P,1) `filter_3D` buffer for the
+    Gaussian centres `xyz` and an iterable of cameras (attributes R, T, image_width, image_height, FoVx, FoVy), all cameras
+    in one kernel instead of ~15 torch kernels per camera."""
+    import math
+
+    import numpy as np
+    _C._require_gpu(xyz, "xyz")
+    x = _prep(xyz.detach(), "xyz", 3)
+    rows, focal_length = [], 0.0
+    for cam in cameras:
+        W, H = cam.image_width, cam.image_height
+        fx = W / (2 * math.tan(cam.FoVx / 2.))
+        fy = H / (2 * math.tan(cam.FoVy / 2.))
+        rows.append(np.concatenate([np.asarray(cam.R, dtype=np.float32).reshape(9), np.asarray(cam.T, dtype=np.float32).reshape(3),
+                                    np.array([fx, fy, W, H], dtype=np.float32)]))
+        focal_length = max(focal_length, fx)
+    if not rows:
+        raise RuntimeError("compute_3D_filter needs at least one camera")
+    table = torch.from_numpy(np.stack(rows)).to(x.device)
+    P = x.size(0)
+    dist = torch.empty(P, dtype=torch.float32, device=x.device)
+    mx = torch.empty(1, dtype=torch.int32, device=x.device)
+    out = torch.empty((P, 1), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib().radegs_compute_filter3d(P, _C._ptr(x), len(rows), _C._ptr(table), float(focal_length), _C._ptr(dist), _C._ptr(mx),
+                                            _C._ptr(out), _C._stream(x.device))
+    if rc != 0:
+        raise RuntimeError(f"radegs_compute_filter3d failed ({rc})")
+    return out

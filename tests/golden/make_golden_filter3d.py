@@ -37,7 +37,23 @@ scales, opacity = gm.get_scaling_n_opacity_with_3D_filter
 cs = torch.from_numpy(rng.standard_normal((P, 3)).astype(np.float32))
 co = torch.from_numpy(rng.standard_normal((P, 1)).astype(np.float32))
 ((scales * cs).sum() + (opacity * co).sum()).backward()
+# ---- compute_3D_filter over a ring of cameras (scene/gaussian_model.py:179-232) ----
+from collections import namedtuple  # noqa: E402
+import math  # noqa: E402
+Cam = namedtuple("Cam", "R T image_width image_height FoVx FoVy")
+xyz = (rng.standard_normal((P, 3)) * 2.0).astype(np.float32)
+cams, rows = [], []
+for c in range(12):
+    ang = 2 * math.pi * c / 12
+    Rwc = np.array([[math.cos(ang), 0, math.sin(ang)], [0, 1, 0], [-math.sin(ang), 0, math.cos(ang)]])
+    T = np.array([0.1 * c, -0.05 * c, 5.0])
+    W, H = (640, 480) if c % 2 else (800, 600)
+    cams.append(Cam(Rwc.T.copy(), T, W, H, math.radians(50 + c), math.radians(40 + c)))
+    rows.append(np.concatenate([cams[-1].R.reshape(9), T, [W, H, cams[-1].FoVx, cams[-1].FoVy]]))
+gm._xyz = torch.from_numpy(xyz)
+gm.compute_3D_filter(cams)
+extra = dict(xyz=xyz, cams=np.stack(rows), filter_out=gm.filter_3D.numpy())
 np.savez_compressed(os.path.join(HERE, "filter3d.npz"), scaling_raw=sc, opacity_raw=op, filter_3D=f3, scales=scales.detach().numpy(),
                     opacity=opacity.detach().numpy(), cot_scales=cs.numpy(), cot_opacity=co.numpy(), g_scaling_raw=gm._scaling.grad.numpy(),
-                    g_opacity_raw=gm._opacity.grad.numpy())
+                    g_opacity_raw=gm._opacity.grad.numpy(), **extra)
 print("ok", scales.shape, opacity.shape, float(opacity.mean()))

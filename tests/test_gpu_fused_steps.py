@@ -238,3 +238,21 @@ def test_fused_adam_matches_torch_golden_and_survives_state_surgery():
     for i, (p, g_, q) in enumerate(zip(ps, gs, p0)):
         ref, _, _ = ao.step(q, g_, np.zeros_like(q), np.zeros_like(q), 1, 1e-3 * (i + 1))
         assert np.abs(p.detach().cpu().numpy() - ref).max() < 1e-6
+
+
+def test_compute_3D_filter_matches_reference_golden():
+    import gaussian_model_ops as gmo
+    from test_filter3d_oracle import cameras_from
+    z = np.load(os.path.join(GOLD, "filter3d.npz"))
+    cams = cameras_from(z)
+    out = gmo.compute_3D_filter(_t(z["xyz"]), cams).cpu().numpy()
+    ref = z["filter_out"]
+    assert out.shape == ref.shape
+    assert (np.abs(out - ref) <= 1e-5 * np.abs(ref)).mean() > 0.999
+    # 1M Gaussians, 150 cameras against the numpy oracle
+    rng = np.random.default_rng(2)
+    xyz = (rng.standard_normal((1_000_000, 3)) * 3.0).astype(np.float32)
+    many = [cams[i % len(cams)]._replace(T=cams[i % len(cams)].T + 0.01 * i) for i in range(150)]
+    out = gmo.compute_3D_filter(_t(xyz), many).cpu().numpy()
+    ref = fo.compute_3D_filter(xyz, many)
+    assert (np.abs(out - ref) <= 1e-5 * np.abs(ref)).mean() > 0.999
