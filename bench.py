@@ -153,6 +153,8 @@ def main():
         dom_ms = ms[dom]
         achieved = ab[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         gpu_ms = sum(grouped.values())
+        kernel_name = {"blend_bwd": "blend_bwd_packed_kernel"}.get(dom, dom + "_kernel")
+        traffic, traffic_note = pmc_traffic(kernel_name, args.config, P, W, H)
         out = {
             "metric": "fwd+bwd Msplats/s @1080p, 1M Gaussians; depth L1 vs ref", "value": round(value, 2), "unit": "Msplats/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -161,8 +163,8 @@ def main():
                                    f"RGB{'+coord' if c else ''}{'+depth' if d else ''}{'+normal' if (c or d) else ''}",
                        "parallelism": f"view-parallel x{world}" + (", RCCL all-reduce of 236 B/Gaussian grads" if world > 1 else ""),
                        "num_rendered": int(R), "visible": Pv},
-            "roofline": {"bound": "hbm", "kernel": {"blend_bwd": "blend_bwd_packed_kernel"}.get(dom, dom + "_kernel"), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": int(ab[dom]), "avg_launch_ms": round(dom_ms, 4)},
             "path_roofline": {"algorithmic_bytes_per_view": int(ab["total"]), "gpu_ms_per_view": round(gpu_ms, 4),
                               "achieved_GBs_gpu_time": round(ab["total"] / (gpu_ms * 1e-3) / 1e9, 1) if gpu_ms > 0 else 0.0,
@@ -177,6 +179,27 @@ def main():
     if launched:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel_name, config, P, W, H):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/*_pmc_per_kernel.json:
+    separate `rocprofv3 --pmc` runs of this same command, TCC_EA0_RDREQ/WRREQ x 64 B as MI355X_MICROARCH.md's HBM section
+    prescribes; its gfx950 note applies: 16-B/lane streaming reads may be under-counted up to 2x).  Counters cannot be
+    collected inside a timed run, so the value is only reported for the workload the pass was made on; else null."""
+    import glob
+    if (config, P, W, H) != ("C2", 1_000_000, 1920, 1080):
+        return None, "no PMC pass for this workload"
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_per_kernel.json")))
+    if not files:
+        return None, "profiles/*_pmc_per_kernel.json not found"
+    try:
+        d = json.load(open(files[-1]))
+        for name, v in d.items():
+            if kernel_name in name:
+                return int((v["TCC_EA0_RDREQ_sum"] + v["TCC_EA0_WRREQ_sum"]) * 64), os.path.basename(files[-1]) + ": (RDREQ+WRREQ)*64 B per launch"
+    except Exception as ex:  # the bench line must not die on a malformed side file
+        return None, f"unreadable PMC summary: {ex}"
+    return None, "kernel not in PMC summary"
 
 
 def cpu_baseline(scene_cpu, seed):
