@@ -61,7 +61,10 @@ def main():
     ap.add_argument("--config", default="C2", help="BASELINE.json config (C1..C5); the headline metric is quoted on C2")
     ap.add_argument("--points", type=int, default=0, help="override the number of Gaussians (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-allreduce", action="store_true", help="run the RCCL gradient all-reduce even at world size 1 (path check)")
+    ap.add_argument("--force-allreduce", action="store_true", help="run the RCCL gradient exchange even at world size 1 (path check)")
+    ap.add_argument("--exchange", choices=("factored", "allreduce"), default="factored",
+                    help="N>1 gradient exchange: 'factored' all-gathers the 12-B dL/dRGB rows and rebuilds the SH gradient locally "
+                         "(161 B/Gaussian over xGMI at N=8), 'allreduce' sums the whole 236-B bucket (413 B/Gaussian)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -79,28 +82,27 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import diff_gaussian_rasterization._C as C
-    from synth_scene import CONFIGS, make_config, to_device, upstream_grads
-    from view_parallel import GradBucket
+    from synth_scene import CONFIGS, jittered_view, make_config, to_device, upstream_grads
+    from view_parallel import FactoredGradExchange, GradBucket
 
     force_allreduce = args.force_allreduce and launched
     over = {}
     if args.points:
         over["P"] = args.points
-    if world > 1:
-        over["pose"] = "random"  # a different camera per rank ...
     cfg = dict(CONFIGS[args.config])
     scene_cpu = make_config(args.config, **over)
-    if world > 1:  # ... over the SAME Gaussians: regenerate rank 0's scene geometry, keep this rank's camera
-        base = make_config(args.config, **{k: v for k, v in over.items() if k != "pose"})
-        cam = make_config(args.config, **dict(over, seed=cfg["seed"] + 1000 + rank, P=8))
-        scene_cpu = base._replace(viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix, campos=cam.campos)
+    if world > 1:  # the SAME Gaussians on every rank, each rank renders its own neighbouring view of them (rank 0: the config's view)
+        scene_cpu = jittered_view(scene_cpu, rank) if rank else scene_cpu
     s = to_device(scene_cpu, dev)
     g = {k: v.to(dev) for k, v in upstream_grads(scene_cpu, cfg["seed"]).items()}
     P, W, H = s.means3D.shape[0], s.W, s.H
     e = torch.Tensor([])
     bucket = None
-    if world > 1 or force_allreduce:
-        bucket = GradBucket(P, s.shs.shape[1], dev)   # backward writes its gradients straight into the bucket
+    if world > 1 or force_allreduce:  # the backward writes its gradients straight into the exchange buffers
+        if args.exchange == "factored":
+            bucket = FactoredGradExchange(P, s.shs.shape[1], s.sh_degree, dev)
+        else:
+            bucket = GradBucket(P, s.shs.shape[1], dev)
         C.GRAD_ALLOCATOR = bucket.allocator
 
     def step():
@@ -113,8 +115,8 @@ def main():
                                             g["mdepth"], g["alpha"], g["normal"], normal, s.shs, s.sh_degree, s.campos, geom, R,
                                             binning, img, alpha, s.require_coord, s.require_depth, False)
         grads = dict(dL_dmeans3D=bw[3], dL_dsh=bw[5], dL_dopacity=bw[2], dL_dscales=bw[6], dL_drotations=bw[7])
-        if bucket is not None:  # the one exchange step of the path: RCCL all-reduce of the gradient bucket
-            grads = bucket.allreduce(average=True)
+        if bucket is not None:  # the one exchange step of the path (RCCL over xGMI)
+            grads = bucket.exchange(s.means3D, s.campos, average=True) if args.exchange == "factored" else bucket.allreduce(average=True)
         return R, radii, grads
 
     def fence():
@@ -161,7 +163,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH degree {s.sh_degree}, fwd+bwd single view per GPU, "
                                    f"RGB{'+coord' if c else ''}{'+depth' if d else ''}{'+normal' if (c or d) else ''}",
-                       "parallelism": f"view-parallel x{world}" + (", RCCL all-reduce of 236 B/Gaussian grads" if world > 1 else ""),
+                       "parallelism": f"view-parallel x{world}" + ((", RCCL all-reduce of 44 B + all-gather of 12 B/Gaussian/view (SH gradient factored)"
+                                                                     if args.exchange == "factored" else ", RCCL all-reduce of 236 B/Gaussian grads")
+                                                                    if world > 1 else ""),
                        "num_rendered": int(R), "visible": Pv},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,

@@ -121,10 +121,19 @@ typedef struct RadegsBwdArgs {
   float* dL_dscale;             /* [P,3] */
   float* dL_drot;               /* [P,4] */
   int require_coord, require_depth, debug;
+  /* optional [P,3]: dL/dRGB of the SH colour with the clamp mask applied.  When given, dL_dsh may be NULL (it is then not
+   * written): the SH gradient is the outer product basis(dir) x this vector and can be rebuilt with
+   * radegs_sh_grad_from_views -- which is how the view-parallel exchange moves 12 instead of 192 bytes per Gaussian. */
+  float* dL_drgb_clamped;
 } RadegsBwdArgs;
 
 /* `accum_alloc` provides the per-Gaussian accumulation scratch (64 or 128 B per Gaussian). */
 int radegs_backward(const RadegsBwdArgs* args, radegs_alloc_fn accum_alloc, void* accum_user, void* stream);
+
+/* dL_dsh[P,M,3] = scale * sum_v basis(normalize(means3D - campos[v])) (x) drgb_clamped[v]   (rows beyond (D+1)^2 zero).
+ * campos: [nviews,3], drgb_clamped: [nviews,P,3] -- the all-gathered per-view outputs of radegs_backward. */
+int radegs_sh_grad_from_views(int P, int D, int M, int nviews, const float* means3D, const float* campos, const float* drgb_clamped,
+                              float scale, float* dL_dsh, void* stream);
 
 /* present[i] = 1 iff Gaussian i passes the near-plane test (view z > 0.2). */
 int radegs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, unsigned char* present,

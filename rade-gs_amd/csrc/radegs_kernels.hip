@@ -1232,6 +1232,7 @@ struct PreBwdArgs {
   CamArgs cam;
   float* dL_dmean2D; float* dL_dcolor; float* dL_dopacity; float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale;
   float* dL_drot;
+  float* dL_drgb_clamped;  // optional [P,3]: dL/dRGB with the clamp mask applied (the view-parallel factored exchange)
 };
 
 // 128 Gaussians per block.  The (P,M,3) SH tensor and its gradient are 192-byte rows at SH degree 3: read or
@@ -1267,6 +1268,7 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
 #pragma unroll
       for (int c = 0; c < 4; c++) a.dL_drot[4 * i + c] = 0;
       if (row) for (int c = 0; c < rowf; c++) row[c] = 0;
+      if (a.dL_drgb_clamped) { a.dL_drgb_clamped[3 * i] = 0; a.dL_drgb_clamped[3 * i + 1] = 0; a.dL_drgb_clamped[3 * i + 2] = 0; }
     } else {
       const Camera cam = load_camera(a.cam);
       SplatAcc acc;
@@ -1329,18 +1331,63 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
         a.dL_dscale[3 * i + c] = o.dscale[c];
       }
       a.dL_dopacity[i] = o.dopacity;
+      if (a.dL_drgb_clamped) {
+        const unsigned cl = (unsigned)a.clamped[idx];
+#pragma unroll
+        for (int c = 0; c < 3; c++) a.dL_drgb_clamped[3 * i + c] = acc.dcolor[c] * (((cl >> c) & 1u) ? 0.f : 1.f);
+      }
 #pragma unroll
       for (int c = 0; c < 6; c++) a.dL_dcov3D[6 * i + c] = o.dcov3D[c];
       *reinterpret_cast<float4*>(a.dL_drot + 4 * i) = make_float4(o.drot[0], o.drot[1], o.drot[2], o.drot[3]);
     }
   }
-  if (have_sh) {
+  if (have_sh && a.dL_dsh) {
     __syncthreads();
     float* dst = a.dL_dsh + (size_t)base * rowf;
     for (int e = tid; e < nrows * rowf; e += kPreBwdThreads) {
       const int g = e / rowf, c = e - g * rowf;
       dst[e] = sh_slab[g * stride + c];
     }
+  }
+}
+
+// dL/dsh[P,M,3] = scale * sum over views v of  w(dir_v) (x) dRGB_v   -- rebuilds the SH gradient of a view-parallel batch
+// from what the ranks all-gathered (12 B per Gaussian per view instead of all-reducing 192 B per Gaussian).
+// Same 128-row LDS slab as preprocess_bwd_kernel for the coalesced write-out.
+__global__ void __launch_bounds__(kPreBwdThreads) sh_grad_from_views_kernel(int P, int D, int M, int nviews, const float* __restrict__ means3D,
+                                                                           const float* __restrict__ campos, const float* __restrict__ drgb,
+                                                                           float scale, float* __restrict__ dL_dsh) {
+  extern __shared__ float sh_slab[];
+  const int tid = threadIdx.x, base = blockIdx.x * kPreBwdThreads, idx = base + tid;
+  const int nrows = min(kPreBwdThreads, P - base);
+  const int rowf = M * 3, stride = rowf + 1;
+  if (idx < P) {
+    float acc[48];
+#pragma unroll
+    for (int k = 0; k < 48; k++) acc[k] = 0.f;
+    const v3 pos = mk3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
+    for (int v = 0; v < nviews; v++) {
+      const float* g = drgb + ((size_t)v * P + idx) * 3;
+      const float gr = g[0], gg = g[1], gb = g[2];
+      if (gr == 0.f && gg == 0.f && gb == 0.f) continue;  // not visible (or fully clamped) in this view
+      const float cp[3] = {campos[3 * v], campos[3 * v + 1], campos[3 * v + 2]};
+      float w[16];
+      sh_basis(D, pos, cp, w);
+#pragma unroll
+      for (int k = 0; k < 16; k++) { acc[3 * k] += w[k] * gr; acc[3 * k + 1] += w[k] * gg; acc[3 * k + 2] += w[k] * gb; }
+    }
+    float* row = sh_slab + tid * stride;
+    const int K3 = 3 * (D + 1) * (D + 1);
+#pragma unroll
+    for (int c = 0; c < 48; c++)
+      if (c < rowf) row[c] = c < K3 ? acc[c] * scale : 0.f;
+    for (int c = 48; c < rowf; c++) row[c] = 0.f;
+  }
+  __syncthreads();
+  float* dst = dL_dsh + (size_t)base * rowf;
+  for (int e = tid; e < nrows * rowf; e += kPreBwdThreads) {
+    const int g = e / rowf, c = e - g * rowf;
+    dst[e] = sh_slab[g * stride + c];
   }
 }
 

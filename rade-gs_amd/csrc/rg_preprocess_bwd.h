@@ -57,7 +57,7 @@ RG_HD v3 sh_bwd(int deg, const float* sh, v3 pos, const float campos[3], unsigne
   const float x = dir.x, y = dir.y, z = dir.z;
 #define SH(k) mk3(sh[3 * (k)], sh[3 * (k) + 1], sh[3 * (k) + 2])
 #define PUT(k, wgt)                                  \
-  {                                                  \
+  if (dsh) {                                         \
     v3 tv = mul((wgt), dRGB);                        \
     dsh[3 * (k)] = tv.x; dsh[3 * (k) + 1] = tv.y; dsh[3 * (k) + 2] = tv.z; \
   }
@@ -105,6 +105,29 @@ RG_HD v3 sh_bwd(int deg, const float* sh, v3 pos, const float campos[3], unsigne
 #undef PUT
   v3 ddir = mk3(dot(dx, dRGB), dot(dy, dRGB), dot(dz, dRGB));
   return dnormvdv(dir_orig, ddir);
+}
+
+// The SH gradient is an outer product: dL/dsh[k] = w_k(dir) * dL/dRGB (clamp-masked).  w_k exactly as sh_bwd's PUT()
+// weights; used to rebuild dL/dsh from per-view (dir, dRGB) pairs after a view-parallel exchange (view_parallel.py).
+RG_HD void sh_basis(int deg, v3 pos, const float campos[3], float w[16]) {
+  v3 dir_orig = sub(pos, mk3(campos[0], campos[1], campos[2]));
+  v3 dir = div(dir_orig, len(dir_orig));
+  const float x = dir.x, y = dir.y, z = dir.z;
+#pragma unroll
+  for (int k = 0; k < 16; k++) w[k] = 0.f;
+  w[0] = RG_C0;
+  if (deg > 0) {
+    w[1] = -RG_C1 * y; w[2] = RG_C1 * z; w[3] = -RG_C1 * x;
+    if (deg > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      w[4] = RG_C2_0 * xy; w[5] = RG_C2_1 * yz; w[6] = RG_C2_2 * (2.f * zz - xx - yy); w[7] = RG_C2_3 * xz; w[8] = RG_C2_4 * (xx - yy);
+      if (deg > 2) {
+        w[9] = RG_C3_0 * y * (3.f * xx - yy); w[10] = RG_C3_1 * xy * z; w[11] = RG_C3_2 * y * (4.f * zz - xx - yy);
+        w[12] = RG_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy); w[13] = RG_C3_4 * x * (4.f * zz - xx - yy);
+        w[14] = RG_C3_5 * z * (xx - yy); w[15] = RG_C3_6 * x * (xx - 3.f * yy);
+      }
+    }
+  }
 }
 
 // scale/quaternion backward (raw dL/dq: the caller's F.normalize owns that Jacobian, backward.cu:554)

@@ -55,7 +55,8 @@ class RadegsBwdArgs(ctypes.Structure):
                 ("dL_dmean2D", ctypes.c_void_p), ("dL_dcolor", ctypes.c_void_p), ("dL_dopacity", ctypes.c_void_p),
                 ("dL_dmean3D", ctypes.c_void_p), ("dL_dcov3D", ctypes.c_void_p), ("dL_dsh", ctypes.c_void_p),
                 ("dL_dscale", ctypes.c_void_p), ("dL_drot", ctypes.c_void_p),
-                ("require_coord", ctypes.c_int), ("require_depth", ctypes.c_int), ("debug", ctypes.c_int)]
+                ("require_coord", ctypes.c_int), ("require_depth", ctypes.c_int), ("debug", ctypes.c_int),
+                ("dL_drgb_clamped", ctypes.c_void_p)]
 
 
 class RadegsIntegrateArgs(ctypes.Structure):
@@ -72,7 +73,7 @@ class RadegsIntegrateArgs(ctypes.Structure):
 
 
 # every symbol include/radegs.h declares
-EXPORTED_SYMBOLS = ("radegs_forward", "radegs_backward", "radegs_mark_visible", "radegs_integrate", "radegs_geometry_bytes", "radegs_image_bytes",
+EXPORTED_SYMBOLS = ("radegs_forward", "radegs_backward", "radegs_mark_visible", "radegs_integrate", "radegs_sh_grad_from_views", "radegs_geometry_bytes", "radegs_image_bytes",
                     "radegs_binning_bytes", "radegs_debug_export", "radegs_last_error", "radegs_version", "radegs_profile_enable",
                     "radegs_profile_num_stages", "radegs_profile_stage_name", "radegs_profile_collect",
                     # fused pre/post steps (bound in graphics_utils.py / gaussian_model_ops.py)
@@ -91,6 +92,10 @@ LAST_POINT_STATE = None
 # or None.  A data-parallel caller points it at slices of ONE flat bucket so that the gradient all-reduce needs no
 # gather copy (rade-gs_amd/view_parallel.GradBucket).  Default: plain torch.empty.
 GRAD_ALLOCATOR = None
+# The allocator may also (a) return a (P,3) tensor for the extra name "dL_drgb_clamped" -- the backward then fills it with
+# dL/dRGB (clamp mask applied) -- and (b) return SKIP_GRAD for "dL_dsh": the (P,M,3) SH gradient is then not written and
+# comes back as None (it is basis(dir) x dL_drgb_clamped; view_parallel.FactoredGradExchange rebuilds the batch sum).
+SKIP_GRAD = object()
 
 
 def library():
@@ -108,6 +113,8 @@ def library():
         L.radegs_backward.argtypes = [ctypes.POINTER(RadegsBwdArgs), _ALLOC_FN, ctypes.c_void_p, ctypes.c_void_p]
         L.radegs_integrate.restype = ctypes.c_int
         L.radegs_integrate.argtypes = [ctypes.POINTER(RadegsIntegrateArgs)] + [_ALLOC_FN, ctypes.c_void_p] * 4 + [ctypes.c_void_p]
+        L.radegs_sh_grad_from_views.restype = ctypes.c_int
+        L.radegs_sh_grad_from_views.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3 + [ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
         L.radegs_mark_visible.restype = ctypes.c_int
         L.radegs_mark_visible.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.radegs_geometry_bytes.restype = ctypes.c_size_t
@@ -249,7 +256,14 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
 
     dL_dmeans3D, dL_dmeans2D, dL_dcolors = mk("dL_dmeans3D", (P, 3)), mk("dL_dmeans2D", (P, 3)), mk("dL_dcolors", (P, 3))
     dL_dopacity, dL_dcov3D = mk("dL_dopacity", (P, 1)), mk("dL_dcov3D", (P, 6))
-    dL_dsh = mk("dL_dsh", (P, M, 3))
+    drgb = None
+    skip_dsh = False
+    if P != 0 and M != 0 and GRAD_ALLOCATOR is not None:
+        drgb = GRAD_ALLOCATOR("dL_drgb_clamped", (P, 3), torch.float32, dev)
+        skip_dsh = drgb is not None and GRAD_ALLOCATOR("dL_dsh", (P, M, 3), torch.float32, dev) is SKIP_GRAD
+        if drgb is not None:
+            assert drgb.shape == torch.Size((P, 3)) and drgb.is_contiguous() and drgb.dtype == torch.float32 and drgb.device == dev
+    dL_dsh = None if skip_dsh else mk("dL_dsh", (P, M, 3))
     dL_dscales, dL_drotations = mk("dL_dscales", (P, 3)), mk("dL_drotations", (P, 4))
     if P != 0:
         bg, m3, col = _f32(background, "bg"), _f32(means3D, "means3D"), _f32(colors, "colors_precomp")
@@ -269,8 +283,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                           float(kernel_size), _ptr(rad), _ptr(nm), _ptr(gb) if gb.numel() else None, _ptr(bb) if bb.numel() else None,
                           _ptr(ib) if ib.numel() else None, _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(g[4]), _ptr(g[5]),
                           _ptr(g[6]), _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
-                          _ptr(dL_dsh) if M else None, _ptr(dL_dscales), _ptr(dL_drotations), int(bool(require_coord)),
-                          int(bool(require_depth)), int(bool(debug)))
+                          _ptr(dL_dsh) if (M and dL_dsh is not None) else None, _ptr(dL_dscales), _ptr(dL_drotations),
+                          int(bool(require_coord)), int(bool(require_depth)), int(bool(debug)), _ptr(drgb))
         with torch.cuda.device(dev):
             rc = L.radegs_backward(ctypes.byref(a), acc.cb, None, _stream(dev))
         if acc.error is not None:
@@ -283,6 +297,23 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             dL_dscales.zero_()
             dL_drotations.zero_()
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def sh_grad_from_views(means3D, campos_all, drgb_all, degree, M, scale=1.0, out=None):
+    """dL_dsh[P,M,3] = scale * sum_v basis(dir_v) (x) drgb_all[v]  (radegs_sh_grad_from_views; campos_all [V,3], drgb_all [V,P,3])."""
+    _require_gpu(means3D, "means3D")
+    L = library()
+    dev = means3D.device
+    P, V = int(means3D.size(0)), int(drgb_all.size(0))
+    m3, cp, dr = _f32(means3D, "means3D"), _f32(campos_all, "campos_all"), _f32(drgb_all, "drgb_all")
+    if V and (tuple(drgb_all.shape) != (V, P, 3) or tuple(campos_all.shape) != (V, 3)):
+        raise RuntimeError("campos_all must be (V,3) and drgb_all (V,P,3)")
+    if out is None:
+        out = torch.empty((P, int(M), 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.radegs_sh_grad_from_views(P, int(degree), int(M), V, _ptr(m3), _ptr(cp), _ptr(dr), float(scale), _ptr(out), _stream(dev))
+    _check(rc, "radegs_sh_grad_from_views")
+    return out
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

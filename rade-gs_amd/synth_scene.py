@@ -157,6 +157,27 @@ def make_config(name, **over) -> Scene:
     return make_scene(**kw)
 
 
+def jittered_view(scene: Scene, seed, angle_deg=2.0, shift=0.05, fovx_deg=60.0) -> Scene:
+    """The same Gaussians seen from a slightly different camera (rotation by `angle_deg` about a random axis, translation by
+    `shift`): what neighbouring training views look like.  Used for the per-rank views of the view-parallel bench so that
+    every rank has the workload of the named config (an unrelated random pose would see almost none of the Gaussians)."""
+    gen = _Rng(777_000 + int(seed))
+    w2c = scene.viewmatrix.double().numpy().T
+    axis = gen.randn(3)
+    axis /= np.linalg.norm(axis)
+    a = math.radians(angle_deg)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    dR = np.eye(3) + math.sin(a) * K + (1 - math.cos(a)) * (K @ K)
+    d = np.eye(4)
+    d[:3, :3] = dR
+    d[:3, 3] = gen.randn(3) * shift
+    w2c = d @ w2c
+    fovx, fovy = 2 * math.atan(scene.tanfovx), 2 * math.atan(scene.tanfovy)
+    viewmatrix = w2c.T.copy()
+    proj = projection_matrix(0.01, 100.0, fovx, fovy).T
+    return scene._replace(viewmatrix=_t(viewmatrix), projmatrix=_t(viewmatrix @ proj), campos=_t(np.linalg.inv(viewmatrix)[3, :3]))
+
+
 def upstream_grads(scene: Scene, seed=0):
     """Fixed random cotangents w_k for the 7 image outputs (loss = sum_k <w_k, out_k>)."""
     gen = _Rng(10_000 + int(seed))

@@ -83,3 +83,22 @@ def test_single_process_is_a_noop():
     from view_parallel import allreduce_gradients
     g = dict(dL_dmeans3D=torch.ones(4, 3))
     assert allreduce_gradients(g)["dL_dmeans3D"] is g["dL_dmeans3D"]
+
+
+def test_factored_exchange_allocator_protocol():
+    """FactoredGradExchange hands the backward in-place views for the 11 small floats, a (P,3) dL/dRGB row buffer, and tells it to
+    skip the (P,M,3) SH gradient; the per-GPU xGMI volume it implies is less than half of the plain all-reduce from N = 2 on."""
+    import diff_gaussian_rasterization._C as C
+    from view_parallel import FactoredGradExchange
+    ex = FactoredGradExchange(100, 16, 3, torch.device("cpu"))
+    assert ex.allocator("dL_dsh", (100, 16, 3), torch.float32, None) is C.SKIP_GRAD
+    assert ex.allocator("dL_drgb_clamped", (100, 3), torch.float32, None).shape == (100, 3)
+    for name, shape in (("dL_dmeans3D", (100, 3)), ("dL_dopacity", (100, 1)), ("dL_dscales", (100, 3)), ("dL_drotations", (100, 4))):
+        v = ex.allocator(name, shape, torch.float32, None)
+        assert v.shape == shape and v.data_ptr() >= ex.small.data_ptr() and v.data_ptr() < ex.small.data_ptr() + ex.small.numel() * 4
+    assert ex.allocator("dL_dcov3D", (100, 6), torch.float32, None) is None
+    assert ex.small.numel() == 100 * 11
+    for n in (2, 4, 8):
+        plain = 2 * (n - 1) / n * 236
+        factored = 2 * (n - 1) / n * 44 + (n - 1) * 12
+        assert factored < 0.5 * plain
