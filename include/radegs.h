@@ -195,6 +195,9 @@ long long radegs_debug_export(const char* name, int P, int R, int width, int hei
  * stage; collect() waits for them, adds each stage's elapsed ms / launch count into the arrays
  * (n >= radegs_profile_num_stages()) and clears the log. */
 void radegs_profile_enable(int on);
+/* stage >= 0: record events for that stage only (each recorded stage boundary costs ~10 us of stream bubble, so a timed
+ * run should select just the kernel it reports); -1: all stages. */
+void radegs_profile_select(int stage);
 int radegs_profile_num_stages(void);
 const char* radegs_profile_stage_name(int i);
 int radegs_profile_collect(float* ms_total, int* count, int n);

@@ -120,7 +120,9 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* m
 constexpr int kEmitCoopThreshold = 16;
 __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32_t* idx_sorted, const uint32_t* offsets,
                                                             const uint32_t* tiles_touched, const float4* splat_a, const int* radii,
-                                                            int gx, int gy, uint32_t* tile_keys, uint32_t* vals) {
+                                                            int gx, int gy, uint32_t* tile_keys, uint32_t* vals, uint32_t cap) {
+  // cap: capacity of tile_keys/vals.  With exact allocation it equals num_rendered; in the speculative path (rg_launch.inc)
+  // it is a prediction and instances beyond it are dropped here (the host detects the overflow and redoes the binning).
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
   uint32_t idx = 0, ntiles = 0, off = 0;
@@ -138,8 +140,10 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32
   if (ntiles && !big) {
     for (int y = y0; y < y1; y++)
       for (int x = x0; x < x1; x++) {
-        tile_keys[off] = (uint32_t)(y * gx + x);
-        vals[off] = idx;
+        if (off < cap) {
+          tile_keys[off] = (uint32_t)(y * gx + x);
+          vals[off] = idx;
+        }
         off++;
       }
   }
@@ -151,13 +155,16 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32
     const int g_x0 = __shfl(x0, src), g_y0 = __shfl(y0, src), g_w = __shfl(x1, src) - g_x0;
     for (uint32_t t = lane; t < g_n; t += 64) {
       const int ty = (int)(t / (uint32_t)g_w), tx = (int)(t - (uint32_t)ty * (uint32_t)g_w);
-      tile_keys[g_off + t] = (uint32_t)((g_y0 + ty) * gx + (g_x0 + tx));
-      vals[g_off + t] = g_idx;
+      if (g_off + t < cap) {
+        tile_keys[g_off + t] = (uint32_t)((g_y0 + ty) * gx + (g_x0 + tx));
+        vals[g_off + t] = g_idx;
+      }
     }
   }
 }
 
-__global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint32_t* keys, uint2* ranges) {
+__global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint32_t* keys, uint2* ranges, const uint32_t* L_dev) {
+  if (L_dev) L = (int)min((uint32_t)L, *L_dev);  // capacity launch, see emit_instances_kernel
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= L) return;
   const uint32_t cur = keys[i];
@@ -656,7 +663,6 @@ struct BlendBwdArgs {
   const float* dL_dpix; const float* dL_dcoord; const float* dL_dmcoord; const float* dL_ddepth; const float* dL_dmdepth;
   const float* dL_dalpha; const float* dL_dnormal;
   float* acc;  // [P][REC] per-Gaussian sums, SplatAcc order
-  int dbg;     // timing experiments only (RADEGS_BWD_DBG): 1 = no atomic, 2 = no reduce+atomic, 3 = no pair bodies
 };
 
 // In: v[i] = this lane's partial sum of component i.  Out (return value): the wave-wide total of
@@ -1112,7 +1118,6 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
         }
       }
       if (!__any(anyc)) continue;
-      if (a.dbg == 3) { if (power[0][0] == 12345.f) a.acc[lane] = C.x + Dq.x + (float)gid; continue; }
       float4 E0, E1, E2;
       if constexpr (COORD) { E0 = lds_b[j * 3 + 0]; E1 = lds_b[j * 3 + 1]; E2 = lds_b[j * 3 + 2]; }
       f2 gv[REC];
@@ -1213,12 +1218,10 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
         gv[15] += u;
       }
       if (!__any(contributed)) continue;
-      if (a.dbg == 2) { if (gv[0][0] == 12345.f) a.acc[lane] = gv[1][1]; continue; }
       float gs[REC];
 #pragma unroll
       for (int i = 0; i < REC; i++) gs[i] = gv[i][0] + gv[i][1];
       const float tot = wave_reduce_scatter<REC, true>(gs, lane);
-      if (a.dbg == 1) { if (tot == 12345.f) a.acc[lane] = tot; continue; }
       if (lane < (COORD ? 25 : 16)) unsafeAtomicAdd(a.acc + (size_t)gid * REC + lane, tot);
     }
   }
@@ -1393,6 +1396,5 @@ __global__ void __launch_bounds__(kPreBwdThreads) sh_grad_from_views_kernel(int 
 
 }  // namespace rg
 
-// The host-side orchestration (C ABI) lives in radegs_api.hip, which includes this file's
-// declarations through rg_launch.h.
+// The host-side orchestration and the C ABI (include/radegs.h) follow; they need the kernels above in scope.
 #include "rg_launch.inc"

@@ -28,8 +28,10 @@ constexpr int kBins = 256;
 
 template <int ITEMS>
 __global__ void __launch_bounds__(kSortThreads) digit_histogram_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
-                                                                       uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblocks) {
+                                                                       uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblocks,
+                                                                       const uint32_t* __restrict__ n_dev) {
   __shared__ uint32_t h[kBins];
+  if (n_dev) n = min(n, *n_dev);  // capacity launch: the real count is still on the device (rg_launch.inc, speculative binning)
   h[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t base = blockIdx.x * (uint32_t)(kSortThreads * ITEMS);
@@ -92,8 +94,10 @@ template <int ITEMS>
 __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
                                                                int shift, uint32_t mask, int nbits, const uint32_t* __restrict__ hist,
-                                                               uint32_t nblocks, const uint32_t* __restrict__ totals) {
+                                                               uint32_t nblocks, const uint32_t* __restrict__ totals,
+                                                               const uint32_t* __restrict__ n_dev) {
   constexpr int BLOCK_ITEMS = kSortThreads * ITEMS, WAVE_ITEMS = 64 * ITEMS;
+  if (n_dev) n = min(n, *n_dev);
   __shared__ uint32_t digit_base[kBins];      // global offset of this block's first item of each digit
   __shared__ uint32_t local_start[kBins];     // position of each digit's first item in the block-local sorted order
   __shared__ uint32_t wave_cnt[4][kBins];     // histogram of each wave's run, then running rank counters
@@ -156,7 +160,7 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const uint32_t* _
   }
   __syncthreads();
   // ---- write out: consecutive local positions of one digit are consecutive global addresses ----
-  const uint32_t count = min((uint32_t)BLOCK_ITEMS, n - block0);
+  const uint32_t count = block0 < n ? min((uint32_t)BLOCK_ITEMS, n - block0) : 0u;
   for (uint32_t pos = tid; pos < count; pos += kSortThreads) {
     const uint32_t key = lds_k[pos];
     const uint32_t digit = (key >> shift) & mask;
@@ -254,8 +258,10 @@ size_t sort_temp_bytes(size_t n) {
 
 // Sorts (keys_in, vals_in) by bits [0, end_bit) of the key into (keys_out, vals_out).  vals_in == nullptr means
 // "values are 0..n-1".  keys_in/vals_in are left untouched; temp must hold sort_temp_bytes(n).
+// n_dev != nullptr: n is a CAPACITY (it sizes the grid and the temp storage) and the number of valid items is min(n, *n_dev),
+// read on the device -- the caller does not have to wait for it.
 hipError_t radix_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
-                                uint32_t* vals_out, size_t n, int end_bit, hipStream_t stream) {
+                                uint32_t* vals_out, size_t n, int end_bit, hipStream_t stream, const uint32_t* n_dev) {
   if (n == 0) return hipSuccess;
   if (temp_bytes < sort_temp_bytes(n)) return hipErrorInvalidValue;
   if (n > 0xFFFFFFFFull - 65536) return hipErrorInvalidValue;
@@ -280,15 +286,15 @@ hipError_t radix_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* k
     uint32_t* dst_k = to_out ? keys_out : tkeys;
     uint32_t* dst_v = to_out ? vals_out : tvals;
     if (items == 16) {
-      hipLaunchKernelGGL(digit_histogram_kernel<16>, dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, (uint32_t)n, shift, mask, hist, nblocks);
+      hipLaunchKernelGGL(digit_histogram_kernel<16>, dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, (uint32_t)n, shift, mask, hist, nblocks, n_dev);
       hipLaunchKernelGGL(scan_rows_kernel, dim3(kBins), dim3(kSortThreads), 0, stream, hist, nblocks, totals);
       hipLaunchKernelGGL(scatter_kernel<16>, dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, src_v, dst_k, dst_v, (uint32_t)n, shift,
-                         mask, nbits, hist, nblocks, totals);
+                         mask, nbits, hist, nblocks, totals, n_dev);
     } else {
-      hipLaunchKernelGGL(digit_histogram_kernel<8>, dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, (uint32_t)n, shift, mask, hist, nblocks);
+      hipLaunchKernelGGL(digit_histogram_kernel<8>, dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, (uint32_t)n, shift, mask, hist, nblocks, n_dev);
       hipLaunchKernelGGL(scan_rows_kernel, dim3(kBins), dim3(kSortThreads), 0, stream, hist, nblocks, totals);
       hipLaunchKernelGGL(scatter_kernel<8>, dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, src_v, dst_k, dst_v, (uint32_t)n, shift,
-                         mask, nbits, hist, nblocks, totals);
+                         mask, nbits, hist, nblocks, totals, n_dev);
     }
     src_k = dst_k;
     src_v = dst_v;

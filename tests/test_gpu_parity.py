@@ -249,3 +249,36 @@ def test_handwritten_sort_matches_device_library():
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][0])
     assert outs[0] == outs[1], outs
+
+
+def test_speculative_binning_matches_exact_path():
+    """The sync-free binning (capacity predicted from the previous call, rg_launch.inc) must give the very same state and images
+    as the exact path, both when the prediction fits and when it is too small (instances dropped -> redone).  The switches are
+    read once per process, hence the subprocesses.  Each process renders three scenes of very different num_rendered in a row
+    (first call exact, then over- and under-predictions), forward + backward."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib, numpy as np, torch\n"
+        "sys.path[:0] = [%r, %r, %r]\n"
+        "from gpu_util import HipRun\n"
+        "from synth_scene import make_scene, upstream_grads\n"
+        "for P, mu, seed in ((30000, 1.5, 1), (30000, 6.0, 2), (4000, 1.5, 3), (60000, 3.0, 4), (60000, 3.0, 4)):\n"
+        "    s = make_scene(P, 320, 200, sh_degree=1, mu_px=mu, seed=seed, require_depth=True)\n"
+        "    h = HipRun(s, 'cuda:0'); st = h.forward_native(); torch.cuda.synchronize()\n"
+        "    pl = h.export('point_list', torch.int32, st[0]); rg = h.export('ranges', torch.int32, 2 * 20 * 13)\n"
+        "    nc = h.export('n_contrib', torch.int32, 2 * 320 * 200)\n"
+        "    img = b''.join(t.cpu().numpy().tobytes() for t in st[1:9])\n"
+        "    out = h.forward(); g = h.backward(upstream_grads(s, seed))\n"
+        "    finite = all(np.isfinite(v).all() for v in g.values() if v is not None)\n"
+        "    print('HASH', st[0], finite, hashlib.sha1(pl.tobytes() + rg.tobytes() + nc.tobytes() + img).hexdigest())\n"
+    ) % tuple(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), p) for p in ("", "rade-gs_amd", "tests"))
+    outs = []
+    for env_over in (dict(RADEGS_SPECULATE="0"), dict(RADEGS_SPECULATE="1"), dict(RADEGS_SPECULATE="1", RADEGS_SPECULATE_HINT="5000")):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_over), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("HASH")]
+        assert len(lines) == 5, lines
+        outs.append(lines)
+    assert outs[0] == outs[1] == outs[2], outs
