@@ -774,7 +774,9 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 2 : (PPL == 2 ? 3 : 5
     dLa[s] = inside ? a.dL_dalpha[pix] : 0.f;
     // background term of dL/dalpha: (-T_final/(1-alpha)) * <bg, dL_dpixel>  (backward.cu:972-975)
     tb[s] = -T_final * (a.bg[0] * dLc[s][0] + a.bg[1] * dLc[s][1] + a.bg[2] * dLc[s][2]);
-    if (NORMAL && inside) {
+    // Pixels nothing blended into (alpha = 0) cannot pass a gradient to any Gaussian; their 1/alpha factors would be inf/NaN and
+    // poison the wave-wide sums through the multiplicative masks, so their geometry cotangents stay zero.
+    if (NORMAL && inside && last_c[s] > 0) {
       const float ww = w_final * w_final;
       const float pny = (pixfy[s] - H / 2.f) / a.focal_y;
       const float ln = sqrtf(pnx * pnx + pny * pny + 1);
@@ -1038,7 +1040,9 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
     }
     float dla = inside ? a.dL_dalpha[pix] : 0.f;
     tb[q][e] = -T_final * (a.bg[0] * dl3[0] + a.bg[1] * dl3[1] + a.bg[2] * dl3[2]);
-    if (NORMAL && inside) {
+    // Pixels nothing blended into (alpha = 0) cannot pass a gradient to any Gaussian; their 1/alpha factors would be inf/NaN and
+    // poison the wave-wide sums through the multiplicative masks, so their geometry cotangents stay zero.
+    if (NORMAL && inside && last_c[s] > 0) {
       const float ww = w_final * w_final;
       const float pny = ((float)py - H / 2.f) / a.focal_y;
       const float ln = sqrtf(pnx * pnx + pny * pny + 1);
