@@ -5,18 +5,18 @@ import torch
 from synth_scene import Scene, to_device
 
 
-def settings_for(s: Scene, device, debug=False):
+def settings_for(s: Scene, device, debug=False, scale_modifier=1.0):
     from diff_gaussian_rasterization import GaussianRasterizationSettings
     return GaussianRasterizationSettings(
         image_height=s.H, image_width=s.W, tanfovx=s.tanfovx, tanfovy=s.tanfovy, kernel_size=s.kernel_size, bg=s.bg.to(device),
-        scale_modifier=1.0, viewmatrix=s.viewmatrix.to(device), projmatrix=s.projmatrix.to(device), sh_degree=s.sh_degree,
+        scale_modifier=scale_modifier, viewmatrix=s.viewmatrix.to(device), projmatrix=s.projmatrix.to(device), sh_degree=s.sh_degree,
         campos=s.campos.to(device), prefiltered=False, require_depth=s.require_depth, require_coord=s.require_coord, debug=debug)
 
 
 class HipRun:
     """forward (+ optional backward) of one view; keeps the private state for index checks."""
 
-    def __init__(self, s: Scene, device="cuda:0", colors=None, cov3D=None, debug=False):
+    def __init__(self, s: Scene, device="cuda:0", colors=None, cov3D=None, debug=False, scale_modifier=1.0):
         import diff_gaussian_rasterization._C as C
         self.C = C
         self.s = s
@@ -31,7 +31,7 @@ class HipRun:
         self.scales = None if cov3D is not None else d.scales.clone().requires_grad_(True)
         self.rotations = None if cov3D is not None else d.rotations.clone().requires_grad_(True)
         self.cov3D = None if cov3D is None else cov3D.to(self.dev).clone().requires_grad_(True)
-        self.rs = settings_for(s, self.dev, debug)
+        self.rs = settings_for(s, self.dev, debug, scale_modifier)
         self.state = None
 
     def forward(self):

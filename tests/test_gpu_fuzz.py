@@ -1,0 +1,34 @@
+"""Randomised parity sweep: scene density, image shapes that are not multiples of the tile, SH degree, 2D-filter size,
+output modes, background colour, scale_modifier, camera pose, opacity regime -- forward indices exact, images within
+tolerance, gradients by the criteria of test_gpu_parity.check_backward (strict-fraction floor relaxed to 97 %: small random
+scenes have short, cancelling per-Gaussian sums).  Seeds are fixed, so a failure reproduces."""
+import numpy as np
+import pytest
+import torch
+
+from synth_scene import make_scene
+from test_gpu_parity import check_backward, check_forward
+
+pytestmark = pytest.mark.gpu
+
+
+def _config(seed):
+    r = np.random.default_rng(1000 + seed)
+    coord, depth = [(False, False), (False, True), (True, False), (True, True)][int(r.integers(0, 4))]
+    kw = dict(P=int(r.integers(300, 12000)), W=int(r.integers(33, 420)), H=int(r.integers(17, 300)), sh_degree=int(r.integers(0, 4)),
+              mu_px=float(r.choice([0.7, 1.5, 4.0, 12.0, 30.0])), seed=int(r.integers(0, 10_000)),
+              kernel_size=float(r.choice([0.0, 0.1, 0.3])), require_coord=coord, require_depth=depth,
+              low_opacity=bool(r.integers(0, 2)), pose=str(r.choice(["identity", "random"])),
+              bg=tuple(float(v) for v in r.random(3)) if r.integers(0, 2) else (0.0, 0.0, 0.0),
+              near_cull_frac=float(r.choice([0.0, 0.02, 0.3])), fovx_deg=float(r.choice([40.0, 60.0, 95.0])))
+    return kw, float(r.choice([1.0, 1.0, 0.5, 1.7]))
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_random_configuration(seed):
+    kw, scale_modifier = _config(seed)
+    if kw["mu_px"] >= 12.0:
+        kw["P"] = min(kw["P"], 2500)  # heavy overdraw: keep the oracle's backward in seconds
+    s = make_scene(**kw)
+    o, h = check_forward(s, scale_modifier=scale_modifier)
+    check_backward(s, o, seed=seed, min_strict=0.97, scale_modifier=scale_modifier)

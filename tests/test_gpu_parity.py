@@ -24,12 +24,12 @@ def _dev():
     return "cuda:0"
 
 
-def check_forward(s, colors=None, cov3D=None):
+def check_forward(s, colors=None, cov3D=None, scale_modifier=1.0):
     from gpu_util import HipRun, outputs_numpy
-    o = oracle_for(s, colors=colors, cov3D=cov3D)
+    o = oracle_for(s, colors=colors, cov3D=cov3D, scale_modifier=scale_modifier)
     R_ref = o.forward()
     ref = o.outputs()
-    h = HipRun(s, _dev(), colors=colors, cov3D=cov3D)
+    h = HipRun(s, _dev(), colors=colors, cov3D=cov3D, scale_modifier=scale_modifier)
     st = h.forward_native()
     torch.cuda.synchronize()
     P, H, W = h.P, s.H, s.W
@@ -56,7 +56,7 @@ def check_forward(s, colors=None, cov3D=None):
     return o, h
 
 
-def check_backward(s, o, colors=None, cov3D=None, seed=0, ill_mask=None, min_strict=0.99):
+def check_backward(s, o, colors=None, cov3D=None, seed=0, ill_mask=None, min_strict=0.99, scale_modifier=1.0):
     """ill_mask: rows (Gaussians) whose covariance is (nearly) singular.  Their per-Gaussian chain rule
     multiplies the accumulated sums by ~1/lambda_min (backward.cu:333-350), so the 1e-7 relative fp32
     reordering noise of the sums is amplified without bound; for those rows the check moves to where the
@@ -66,7 +66,7 @@ def check_backward(s, o, colors=None, cov3D=None, seed=0, ill_mask=None, min_str
     from gpu_util import HipRun
     g = upstream_grads(s, seed)
     ref = oracle_backward(o, g)
-    h = HipRun(s, _dev(), colors=colors, cov3D=cov3D)
+    h = HipRun(s, _dev(), colors=colors, cov3D=cov3D, scale_modifier=scale_modifier)
     h.forward()
     C.KEEP_ACC = True
     try:
@@ -100,7 +100,7 @@ def check_backward(s, o, colors=None, cov3D=None, seed=0, ill_mask=None, min_str
     # Criterion 2 (accuracy): against the fp64 oracle the HIP gradients are as accurate as the fp32 oracle.
     report = {}
     rows = np.ones(P, bool) if ill_mask is None else ~ill_mask
-    nf = grad_noise_floor(s, g, colors=colors, cov3D=cov3D) if P <= 20000 else None
+    nf = grad_noise_floor(s, g, colors=colors, cov3D=cov3D, scale_modifier=scale_modifier) if P <= 20000 else None
     floor, g64 = nf if nf is not None else ({}, {})
     for k, b in ref.items():
         a = got[k]

@@ -9,11 +9,11 @@ from synth_scene import Scene, make_scene, upstream_grads  # noqa: F401
 ATOL, RTOL = 1e-5, 1e-4
 
 
-def oracle_for(s: Scene, precision=32, colors=None, cov3D=None, nthreads=None):
+def oracle_for(s: Scene, precision=32, colors=None, cov3D=None, nthreads=None, scale_modifier=1.0):
     kw = dict(bg=s.bg, means3D=s.means3D, opacities=s.opacities, viewmatrix=s.viewmatrix, projmatrix=s.projmatrix, campos=s.campos,
               tanfovx=s.tanfovx, tanfovy=s.tanfovy, image_height=s.H, image_width=s.W, sh_degree=s.sh_degree,
               kernel_size=s.kernel_size, require_coord=s.require_coord, require_depth=s.require_depth, precision=precision,
-              nthreads=nthreads)
+              nthreads=nthreads, scale_modifier=scale_modifier)
     if colors is None:
         kw["shs"] = s.shs
     else:
@@ -53,16 +53,16 @@ def cov3d_of(s: Scene):
     return torch.stack([Sg[:, 0, 0], Sg[:, 0, 1], Sg[:, 0, 2], Sg[:, 1, 1], Sg[:, 1, 2], Sg[:, 2, 2]], 1).float().contiguous()
 
 
-def grad_noise_floor(scene, g, colors=None, cov3D=None):
+def grad_noise_floor(scene, g, colors=None, cov3D=None, scale_modifier=1.0):
     """fp32 conditioning of the backward.  The algorithm itself (reference arithmetic: T recovered by
     repeated division, differences of nearly equal blended values, sums of +/- terms) is only accurate to
     ~1e-3 relative in fp32 -- measured as |oracle_fp32 - oracle_fp64| per gradient tensor.  Two correct fp32
     implementations that round differently (fma vs mul+add, hardware exp/rcp) can therefore differ by a
     fraction of this floor even when both are as close to the exact gradient as fp32 allows.
     Returns {name: max |fp32 - fp64|} or None if the fp64 run took different thresholded decisions."""
-    o32 = oracle_for(scene, colors=colors, cov3D=cov3D, nthreads=1)
+    o32 = oracle_for(scene, colors=colors, cov3D=cov3D, nthreads=1, scale_modifier=scale_modifier)
     o32.forward()
-    o64 = oracle_for(scene, precision=64, colors=colors, cov3D=cov3D, nthreads=1)
+    o64 = oracle_for(scene, precision=64, colors=colors, cov3D=cov3D, nthreads=1, scale_modifier=scale_modifier)
     o64.forward()
     if not (np.array_equal(o32.get("n_contrib"), o64.get("n_contrib")) and np.array_equal(o32.get("point_list"), o64.get("point_list"))):
         return None
