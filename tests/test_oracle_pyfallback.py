@@ -39,3 +39,15 @@ def test_cov3d_and_sh_colour_match_the_reference_python(deg):
     assert same_radii > 0.999                                 # a last-bit cov3D difference may move a radius across ceil()
     for k in (0, 4, 5, 6, 7):
         assert close(img2[k], img[k], atol=2e-4, rtol=1e-3).mean() > 0.999
+
+
+def test_camera_matrices_match_the_reference_conventions():
+    """synth_scene's viewmatrix / projmatrix / campos against scene/cameras.py:54-57 evaluated with the reference's
+    getWorld2View2 / getProjectionMatrix (tests/golden/make_golden_cameras.py)."""
+    C = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cameras.npz"))
+    for i in range(3):
+        W, H, fov, seed, rnd = C[f"args_{i}"]
+        s = make_scene(8, int(W), int(H), seed=int(seed), pose="random" if rnd else "identity", fovx_deg=float(fov))
+        assert np.allclose(s.viewmatrix.numpy(), C[f"view_{i}"], atol=1e-6)
+        assert np.allclose(s.projmatrix.numpy(), C[f"proj_{i}"], rtol=1e-5, atol=1e-5)
+        assert np.allclose(s.campos.numpy(), C[f"campos_{i}"], atol=1e-5)
