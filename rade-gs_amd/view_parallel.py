@@ -128,7 +128,8 @@ class FactoredGradExchange:
     def exchange(self, means3D, campos, average: bool = True):
         scale = 1.0
         if dist.is_available() and dist.is_initialized():
-            h1 = dist.all_gather_into_tensor(self.gathered, self.drgb, group=self.group, async_op=True)
+            # output in the concatenated form (world*P, 3): the layout every backend's all_gather_into_tensor accepts
+            h1 = dist.all_gather_into_tensor(self.gathered.view(-1, 3), self.drgb, group=self.group, async_op=True)
             h2 = dist.all_gather_into_tensor(self.campos_all, campos.reshape(1, 3).to(torch.float32).contiguous(), group=self.group, async_op=True)
             dist.all_reduce(self.small, op=dist.ReduceOp.SUM, group=self.group)
             h1.wait()

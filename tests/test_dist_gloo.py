@@ -102,3 +102,70 @@ def test_factored_exchange_allocator_protocol():
         plain = 2 * (n - 1) / n * 236
         factored = 2 * (n - 1) / n * 44 + (n - 1) * 12
         assert factored < 0.5 * plain
+
+
+def _sh_weights_np(deg, pos, campos):
+    """TEST stand-in for the HIP rebuild kernel's basis (the PUT() weights of rg_preprocess_bwd.h::sh_bwd, degree <= 1 here)."""
+    d = pos - campos[None]
+    d = d / np.linalg.norm(d, axis=1, keepdims=True)
+    w = np.zeros((pos.shape[0], 16), np.float64)
+    w[:, 0] = 0.28209479177387814
+    if deg > 0:
+        c1 = 0.4886025119029199
+        w[:, 1], w[:, 2], w[:, 3] = -c1 * d[:, 1], c1 * d[:, 2], -c1 * d[:, 0]
+    return w
+
+
+def _factored_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "rade-gs_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import diff_gaussian_rasterization._C as C
+    from view_parallel import FactoredGradExchange
+    P, M, D = 301, 16, 1
+
+    def rebuild(means3D, campos_all, drgb_all, degree, M_, scale=1.0, out=None):   # numpy stand-in: the product's is a HIP kernel
+        acc = np.zeros((P, 16, 3))
+        for v in range(drgb_all.shape[0]):
+            w = _sh_weights_np(degree, means3D.double().numpy(), campos_all[v].double().numpy())
+            acc += w[:, :, None] * drgb_all[v].double().numpy()[:, None, :]
+        out.copy_(torch.from_numpy(acc * scale).float())
+        return out
+    C.sh_grad_from_views = rebuild
+    ex = FactoredGradExchange(P, M, D, torch.device("cpu"))
+    g = torch.Generator().manual_seed(500 + rank)
+    means3D = torch.randn(P, 3, generator=torch.Generator().manual_seed(7))      # replicated Gaussians
+    campos = torch.randn(3, generator=g) * 5                                       # this rank's camera
+    drgb = torch.randn(P, 3, generator=g)
+    drgb[::7] = 0                                                                  # invisible in this view
+    for k, v in ex.views.items():
+        v.copy_(torch.randn(v.shape, generator=g))
+    small_before = ex.small.clone()
+    ex.allocator("dL_drgb_clamped", (P, 3), torch.float32, None).copy_(drgb)
+    out = ex.exchange(means3D, campos, average=True)
+    torch.save({"out": {k: v.clone() for k, v in out.items()}, "small": small_before, "drgb": drgb, "campos": campos, "means3D": means3D},
+               os.path.join(out_dir, f"f{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_factored_exchange_two_ranks(tmp_path):
+    """The collectives of FactoredGradExchange under gloo, world_size 2 (all-gather of the dL/dRGB rows and camera positions in
+    rank order, all-reduce of the small bucket, averaging); the rebuild kernel is replaced by a numpy stand-in in the workers."""
+    world = 2
+    mp.spawn(_factored_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"f{r}.pt")) for r in range(world)]
+    P = 301
+    expect_sh = np.zeros((P, 16, 3))
+    for r in range(world):
+        w = _sh_weights_np(1, outs[r]["means3D"].double().numpy(), outs[r]["campos"].double().numpy())
+        expect_sh += w[:, :, None] * outs[r]["drgb"].double().numpy()[:, None, :]
+    expect_sh /= world
+    small = (outs[0]["small"] + outs[1]["small"]) / world
+    for r in range(world):
+        o = outs[r]["out"]
+        np.testing.assert_allclose(o["dL_dsh"].numpy(), expect_sh, rtol=1e-5, atol=1e-6)
+        flat = torch.cat([o[k].reshape(-1) for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations")])
+        torch.testing.assert_close(flat, small)
+    assert torch.equal(outs[0]["out"]["dL_dsh"], outs[1]["out"]["dL_dsh"])
