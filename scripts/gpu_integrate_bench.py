@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="C2")
 ap.add_argument("--points-per-gaussian", type=int, default=4)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--max-points", type=int, default=0, help="truncate the point set (isolates the image pass)")
 ap.add_argument("--check", action="store_true", help="compare with the oracle (slow)")
 a = ap.parse_args()
 s = make_config(a.config, kernel_size=0.0)
@@ -22,6 +23,8 @@ rng = np.random.default_rng(0)
 k = a.points_per_gaussian
 pts = (s.means3D.numpy()[:, None, :] + rng.normal(size=(P, k, 3)).astype(np.float32) * 1.5 * s.scales.numpy().max(1)[:, None, None])
 pts = np.ascontiguousarray(pts.reshape(-1, 3), dtype=np.float32)
+if a.max_points:
+    pts = pts[rng.permutation(len(pts))[:a.max_points]].copy()
 dev = torch.device("cuda:0")
 d = to_device(s, dev)
 r = GaussianRasterizer(settings_for(s, dev))
