@@ -56,7 +56,8 @@ def check_forward(s, colors=None, cov3D=None, scale_modifier=1.0):
     return o, h
 
 
-def check_backward(s, o, colors=None, cov3D=None, seed=0, ill_mask=None, min_strict=0.99, scale_modifier=1.0):
+def check_backward(s, o, colors=None, cov3D=None, seed=0, ill_mask=None, min_strict=0.99, scale_modifier=1.0, rms_factor=1.1,
+                   max_factor=1.25, band_factor=1.0):
     """ill_mask: rows (Gaussians) whose covariance is (nearly) singular.  Their per-Gaussian chain rule
     multiplies the accumulated sums by ~1/lambda_min (backward.cu:333-350), so the 1e-7 relative fp32
     reordering noise of the sums is amplified without bound; for those rows the check moves to where the
@@ -111,15 +112,15 @@ def check_backward(s, o, colors=None, cov3D=None, seed=0, ill_mask=None, min_str
         a, b = a[rows], b[rows]
         strict = frac_close(a, b)
         scale = float(np.abs(b).max()) + 1e-30
-        band = ATOL + max(2e-6 * scale, 0.25 * floor.get(k, 0.0))
+        band = ATOL + band_factor * max(2e-6 * scale, 0.25 * floor.get(k, 0.0))
         report[k] = strict
         assert strict > min_strict, f"{k}: only {strict:.4f} within 1e-5/1e-4"
         assert close(a, b, atol=band, rtol=1e-3).all(), f"{k}: max abs diff {np.abs(a - b).max():.3e} (scale {scale:.3e}, fp32 floor {floor.get(k)})"
         if k in g64 and ill_mask is None:
             c = g64[k].reshape(got[k].shape)[rows]
             e_hip, e_ref = np.abs(a.astype(np.float64) - c), np.abs(b.astype(np.float64) - c)
-            assert np.sqrt((e_hip ** 2).mean()) <= 1.1 * np.sqrt((e_ref ** 2).mean()) + 1e-7, f"{k}: rms error vs fp64 worse than the fp32 oracle's"
-            assert e_hip.max() <= 1.25 * e_ref.max() + ATOL, f"{k}: max error vs fp64 {e_hip.max():.3e} vs oracle's {e_ref.max():.3e}"
+            assert np.sqrt((e_hip ** 2).mean()) <= rms_factor * np.sqrt((e_ref ** 2).mean()) + 1e-7, f"{k}: rms error vs fp64 worse than the fp32 oracle's"
+            assert e_hip.max() <= max_factor * e_ref.max() + ATOL, f"{k}: max error vs fp64 {e_hip.max():.3e} vs oracle's {e_ref.max():.3e}"
     return report
 
 
