@@ -136,3 +136,25 @@ def test_integrate_C2_full_size():
     # size-independent properties: every projected point is counted once; integrated opacity never exceeds 1
     assert got[0][8].sum() == (got[3].any(axis=1)).sum()
     assert (got[1] <= 1.0 + 1e-6).all() and (got[1] >= 0).all()
+
+
+import os  # noqa: E402
+
+_ISPEC = os.environ.get("RADEGS_FUZZ_SEEDS", "0:6")
+_ISEEDS = [int(v) for v in _ISPEC.split(",")] if "," in _ISPEC else list(range(*(int(v) for v in _ISPEC.split(":"))))
+
+
+@pytest.mark.parametrize("seed", _ISEEDS)
+def test_integrate_random_configuration(seed):
+    """Randomised sweep of integrate(): image shapes off the tile grid, densities from empty pixels to heavy overdraw, SH degree,
+    pose, opacity regime, background, point clouds from sparse to ~10 per pixel, some points outside the frustum."""
+    r = np.random.default_rng(3000 + seed)
+    mu = float(r.choice([0.7, 1.5, 4.0, 12.0]))
+    P = int(r.integers(200, 6000)) if mu < 12 else int(r.integers(200, 1500))
+    W, H = int(r.integers(33, 300)), int(r.integers(17, 220))
+    s = make_scene(P, W, H, sh_degree=int(r.integers(0, 4)), mu_px=mu, seed=int(r.integers(0, 10_000)), kernel_size=0.0,
+                   pose=str(r.choice(["identity", "random"])), require_coord=False, require_depth=True, low_opacity=bool(r.integers(0, 2)),
+                   bg=tuple(float(v) for v in r.random(3)) if r.integers(0, 2) else (0.0, 0.0, 0.0), fovx_deg=float(r.choice([40.0, 60.0, 95.0])),
+                   near_cull_frac=float(r.choice([0.0, 0.02, 0.3])))
+    n = int(r.choice([50, 2000, 10 * W * H]))
+    check(s, _points(s, n, seed, spread=float(r.choice([0.02, 0.3])), far=int(r.integers(0, 200))), min_projected=1)
