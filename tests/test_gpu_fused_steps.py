@@ -256,3 +256,43 @@ def test_compute_3D_filter_matches_reference_golden():
     out = gmo.compute_3D_filter(_t(xyz), many).cpu().numpy()
     ref = fo.compute_3D_filter(xyz, many)
     assert (np.abs(out - ref) <= 1e-5 * np.abs(ref)).mean() > 0.999
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (2, 3), (5, 7), (11, 11), (16, 64), (64, 16), (65, 17), (130, 33), (257, 5)])
+def test_losses_on_odd_image_sizes(W, H):
+    """Images smaller than the 11-tap SSIM window / the 3x3 normal stencil, and sizes off the 64x16 kernel tiles."""
+    import graphics_utils as gu
+    import loss_utils as lu
+    from oracle import loss_oracle as lo
+    rng = np.random.default_rng(W * 1000 + H)
+    gt = rng.random((3, H, W)).astype(np.float32)
+    img = np.clip(gt + 0.1 * rng.standard_normal((3, H, W)), 0, 1).astype(np.float32)
+    a = _t(img, True)
+    loss = lu.photometric_loss(a, _t(gt), 0.2)
+    loss.backward()
+    assert abs(loss.item() - lo.rgb_loss(img.astype(np.float64), gt.astype(np.float64), 0.2)) < 5e-6
+    ref = lo.rgb_loss_bwd(img.astype(np.float64), gt.astype(np.float64), 0.2)
+    assert np.abs(a.grad.cpu().numpy() - ref).max() < 2e-4 * np.abs(ref).max() + 1e-9
+    # normals + consistency loss
+    fovx = 1.0
+    fovy = 2 * np.arctan(np.tan(fovx / 2) * H / W)
+    view = View(W, H, fovx, float(fovy))
+    d1 = (3 + rng.random((1, H, W))).astype(np.float32)
+    d2 = (3 + rng.random((1, H, W))).astype(np.float32)
+    rn = rng.standard_normal((3, H, W)).astype(np.float32)
+    t1, t2, tr = _t(d1, True), _t(d2, True), _t(rn, True)
+    nm = gu.depth_double_to_normal(view, t1, t2)
+    ref_nm = no.depth_double_to_normal(d1.astype(np.float64), d2.astype(np.float64), W, H, fovx, float(fovy))
+    assert np.abs(nm.detach().cpu().numpy() - ref_nm).max() < 5e-5
+    l2 = gu.normal_consistency_loss(view, tr, t1, t2, 0.6)
+    l2.backward()
+    assert abs(l2.item() - no.consistency_loss(rn.astype(np.float64), ref_nm)) < 1e-5
+    for t in (t1, t2, tr):
+        assert torch.isfinite(t.grad).all()
+    g_rn, g_nm = no.consistency_loss_bwd(rn.astype(np.float64), ref_nm)
+    assert np.abs(tr.grad.cpu().numpy() - g_rn).max() < 1e-4 * (np.abs(g_rn).max() + 1e-12) + 1e-9
+    gd1, gd2 = no.depth_double_to_normal_bwd(d1.astype(np.float64), d2.astype(np.float64), W, H, fovx, float(fovy), g_nm)
+    for t, ref_g in ((t1, gd1), (t2, gd2)):
+        sc = np.abs(ref_g).max() + 1e-12
+        assert np.median(np.abs(t.grad.cpu().numpy() - ref_g)) < 1e-4 * sc
+        assert np.abs(t.grad.cpu().numpy() - ref_g).max() < 5e-2 * sc
