@@ -285,6 +285,14 @@ typedef struct RadegsAdamTensor {
 } RadegsAdamTensor;
 int radegs_adam_step(int count, const RadegsAdamTensor* tensors, double beta1, double beta2, double eps, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * simple_knn._C.distCUDA2 (scene/gaussian_model.py:315): out[i] = mean of the squared distances from points[i] to its 3
+ * nearest neighbours.  The reference imports it from the un-vendored `simple-knn` submodule; restated from that library's
+ * published algorithm (Morton order + boxes of 1024 points + exact rejection search).  points: [P,3] float32 device.
+ * --------------------------------------------------------------------------------------------------------------- */
+size_t radegs_knn_scratch_bytes(int P);
+int radegs_knn_mean_dist2(int P, const float* points, void* scratch, float* out /* [P] */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

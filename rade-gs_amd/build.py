@@ -30,6 +30,7 @@ UNITS = {
     "radegs_filter3d": ["radegs_filter3d.hip", os.path.join("..", "..", "include", "radegs.h")],
     "radegs_photometric": ["radegs_photometric.hip", os.path.join("..", "..", "include", "radegs.h")],
     "radegs_adam": ["radegs_adam.hip", os.path.join("..", "..", "include", "radegs.h")],
+    "radegs_knn": ["radegs_knn.hip", "rg_prims.h", os.path.join("..", "..", "include", "radegs.h")],
 }
 # Units outside the rasterizer's decision chain have no bit-exactness contract with the oracle: let them contract to fma.
 UNIT_FLAGS = {"radegs_normals": ["-ffp-contract=fast"], "radegs_filter3d": ["-ffp-contract=fast"],

@@ -81,7 +81,8 @@ EXPORTED_SYMBOLS = ("radegs_forward", "radegs_backward", "radegs_mark_visible", 
                     "radegs_normal_loss_forward", "radegs_normal_loss_backward", "radegs_normals_last_error",
                     "radegs_filter3d_forward", "radegs_filter3d_backward", "radegs_compute_filter3d",
                     "radegs_photometric_scratch_bytes",
-                    "radegs_photometric_forward", "radegs_photometric_backward", "radegs_adam_step")
+                    "radegs_photometric_forward", "radegs_photometric_backward", "radegs_adam_step", "radegs_knn_scratch_bytes",
+                    "radegs_knn_mean_dist2")
 
 _lib = None
 # test hook: when True, the per-Gaussian accumulation scratch of the last backward is kept in LAST_ACC

@@ -296,3 +296,24 @@ def test_losses_on_odd_image_sizes(W, H):
         sc = np.abs(ref_g).max() + 1e-12
         assert np.median(np.abs(t.grad.cpu().numpy() - ref_g)) < 1e-4 * sc
         assert np.abs(t.grad.cpu().numpy() - ref_g).max() < 5e-2 * sc
+
+
+@pytest.mark.parametrize("P,kind", [(4, "uniform"), (100, "uniform"), (5000, "clustered"), (300_000, "uniform"), (200_000, "surface")])
+def test_simple_knn_distcuda2(P, kind):
+    """simple_knn._C.distCUDA2 against an exact k-d tree (oracle/knn_oracle.py)."""
+    from oracle import knn_oracle
+    from simple_knn._C import distCUDA2
+    rng = np.random.default_rng(P)
+    if kind == "uniform":
+        pts = rng.random((P, 3))
+    elif kind == "clustered":
+        pts = rng.standard_normal((P, 3)) * 0.01 + rng.integers(0, 5, (P, 1)) * 3.0
+        pts[:50] = pts[0]                                   # duplicates: zero distances
+    else:
+        uv = rng.random((P, 2))
+        pts = np.stack([uv[:, 0] * 4, uv[:, 1] * 2, 0.1 * np.sin(6 * uv[:, 0]) * np.cos(5 * uv[:, 1])], 1)
+    pts = pts.astype(np.float32)
+    got = distCUDA2(_t(pts)).cpu().numpy()
+    ref = knn_oracle.mean_dist2_3nn(pts)
+    assert got.shape == (P,) and np.isfinite(got).all()
+    assert np.allclose(got, ref, rtol=2e-4, atol=1e-12 + 1e-6 * ref.max())
