@@ -470,8 +470,48 @@ __device__ __forceinline__ int xcd_band_remap(int b, int n) {
   return xcd * q + (xcd < r ? xcd : r) + loc;
 }
 
-template <bool COORD, bool DEPTH, int PPL>
+// ---- GROUPED variants (PPL = 2): four 16-lane groups per wave, each walking its OWN culled entry stream -------------------
+// A wave iteration costs the same whether 1 or 64 lanes blend, so what matters is how many iterations a strip needs.  With
+// one stream per wave that is every entry whose {alpha >= 1/255} ellipse touches the 16x8 strip (C2: 256 per strip, 226 of
+// them with a real candidate); a pixel itself needs 65.  Here each DPP row of 16 lanes owns a compact 8x4 block of the strip
+// (2 pixels per lane, rows 2 apart), culls the batch against ITS block (four ballots at staging) and pops its own next entry
+// every iteration: per-lane ctz on a VGPR mask, per-row LDS broadcast reads.  The wave runs max-over-rows iterations
+// (C2: 170 instead of 256).  In the backward the per-Gaussian reduction then IS the row-local part of the butterfly (the four
+// DPP stages, no cross-row exchange) and one 64-lane atomic instruction updates four accumulator lines, one per row.
+struct GroupGeom { int px, py_first, py_step; float rx0, rx1, ry0, ry1; };
+template <bool GROUPED, int PPL>
+__device__ __forceinline__ GroupGeom lane_geometry(int lane, int tile_x, int tile_y, int sub) {
+  GroupGeom g;
+  if constexpr (GROUPED) {
+    const int grp = lane >> 4, l = lane & 15;
+    const int bx = tile_x * 16 + (grp & 1) * 8, by = tile_y * 16 + sub * 8 + (grp >> 1) * 4;
+    g.px = bx + (l & 7); g.py_first = by + (l >> 3); g.py_step = 2;
+    g.rx0 = (float)bx; g.rx1 = g.rx0 + 7.0f; g.ry0 = (float)by; g.ry1 = g.ry0 + 3.0f;
+  } else {
+    g.px = tile_x * 16 + (lane & 15); g.py_first = tile_y * 16 + sub * (4 * PPL) + (lane >> 4); g.py_step = 4;
+    g.rx0 = (float)(tile_x * 16); g.rx1 = g.rx0 + 15.0f; g.ry0 = (float)(tile_y * 16 + sub * (4 * PPL)); g.ry1 = g.ry0 + (float)(4 * PPL - 1);
+  }
+  return g;
+}
+// the batch's survivor mask of this lane's group: lane k holds entry k's record and tests it against all four 8x4 blocks
+// niter (wave-uniform, scalar): the longest of the four streams = the number of iterations the wave runs for this batch
+__device__ __forceinline__ uint64_t group_masks(bool valid, const float4 q0, const float4 q1, int tile_x, int tile_y, int sub, int lane,
+                                                int& niter) {
+  uint64_t mine = 0;
+  niter = 0;
+#pragma unroll
+  for (int grp = 0; grp < 4; grp++) {
+    const float bx = (float)(tile_x * 16 + (grp & 1) * 8), by = (float)(tile_y * 16 + sub * 8 + (grp >> 1) * 4);
+    const uint64_t m = __ballot(valid && entry_may_touch(q0, q1, bx, bx + 7.0f, by, by + 3.0f));
+    niter = max(niter, (int)__popcll(m));
+    if ((lane >> 4) == grp) mine = m;
+  }
+  return mine;
+}
+
+template <bool COORD, bool DEPTH, int PPL, bool GROUPED = false>
 __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
+  static_assert(!GROUPED || PPL == 2, "grouped streams are built for 2 pixels per lane");
   constexpr bool NORMAL = COORD || DEPTH;
   constexpr int WPT = 4 / PPL;  // waves per tile
   __shared__ float4 lds_a[65 * 4];
@@ -480,15 +520,15 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
   const int item = xcd_band_remap(blockIdx.x, gridDim.x);
   const int tile = item / WPT, sub = item - tile * WPT;
   const int tile_x = tile % a.gx, tile_y = tile / a.gx;
-  const int lane = threadIdx.x, lx = lane & 15, lr = lane >> 4;
-  const int px = tile_x * 16 + lx;
-  const int py0 = tile_y * 16 + sub * (4 * PPL) + lr;  // slot s -> row py0 + 4*s
+  const int lane = threadIdx.x;
+  const GroupGeom geo = lane_geometry<GROUPED, PPL>(lane, tile_x, tile_y, sub);
+  const int px = geo.px;
+  const int py0 = geo.py_first;  // slot s -> row py0 + py_step*s
   const int W = a.W, H = a.H;
   const size_t HW = (size_t)H * W;
   const float pixfx = (float)px;
-  // pixel rectangle owned by this wave (for batch culling)
-  const float reg_x0 = (float)(tile_x * 16), reg_x1 = reg_x0 + 15.0f;
-  const float reg_y0 = (float)(tile_y * 16 + sub * (4 * PPL)), reg_y1 = reg_y0 + (float)(4 * PPL - 1);
+  // pixel rectangle owned by this wave (for batch culling; per group in the GROUPED variant)
+  const float reg_x0 = geo.rx0, reg_x1 = geo.rx1, reg_y0 = geo.ry0, reg_y1 = geo.ry1;
 
   const uint2 range = a.ranges[tile];
   const int n = (int)(range.y - range.x);
@@ -502,7 +542,7 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
   bool inside[PPL];
 #pragma unroll
   for (int s = 0; s < PPL; s++) {
-    const int py = py0 + 4 * s;
+    const int py = py0 + geo.py_step * s;
     pixfy[s] = (float)py;
     inside[s] = px < W && py < H;
     T[s] = 1.0f; Tw[s] = inside[s] ? 1.0f : 0.0f; Cr[s] = Cg[s] = Cb[s] = 0.f; weight[s] = 0.f;
@@ -526,6 +566,7 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
     __syncthreads();
     const int k = base + lane;
     bool rel_lane = false;
+    float4 gq0 = make_float4(0.f, 0.f, 0.f, 0.f), gq1 = gq0;
     if (k < n) {
       const uint32_t g = a.point_list[range.x + k];
       const float4* src = a.splat_a + 4 * (size_t)g;
@@ -535,13 +576,18 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
         const float4* sb = a.splat_b + 3 * (size_t)g;
         lds_b[lane * 3 + 0] = sb[0]; lds_b[lane * 3 + 1] = sb[1]; lds_b[lane * 3 + 2] = sb[2];
       }
-      rel_lane = entry_may_touch(q0, q1, reg_x0, reg_x1, reg_y0, reg_y1);
+      if constexpr (!GROUPED) rel_lane = entry_may_touch(q0, q1, reg_x0, reg_x1, reg_y0, reg_y1);
+      if constexpr (GROUPED) { gq0 = q0; gq1 = q1; }
     }
-    uint64_t rel = __ballot(rel_lane);
+    uint64_t rel;
+    int niter = 0;
+    if constexpr (GROUPED) rel = group_masks(k < n, gq0, gq1, tile_x, tile_y, sub, lane, niter);  // per-lane (per-row) value
+    else { rel = __ballot(rel_lane); niter = (int)__popcll(rel); }
     __syncthreads();
-    while (rel != 0 && !all_done) {
-      const int j = __builtin_ctzll(rel);
-      rel &= rel - 1;
+    for (int it = 0; it < niter && !all_done; it++) {   // scalar trip count in both variants
+      const bool idle = GROUPED && rel == 0;   // this row's stream is exhausted for the batch
+      const int j = idle ? 0 : __builtin_ctzll(rel);
+      rel &= rel - 1;                           // 0 stays 0
       const float4 A = lds_a[j * 4 + 0], B = lds_a[j * 4 + 1];  // {mx,my,cx,cy} {cz,op,thr,ts}
       const float dx = A.x - pixfx;
       const float a_x = (A.z * dx) * dx;
@@ -552,10 +598,10 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
       for (int s = 0; s < PPL; s++) {
         const float dy = A.y - pixfy[s];
         power[s] = splat_power(a_x, b_xy, B.x, dy);
-        cand[s] = !(power[s] > 0.0f) && !(power[s] < B.z);
+        cand[s] = !idle && !(power[s] > 0.0f) && !(power[s] < B.z);
         anyc = anyc || cand[s];
       }
-      if (!__any(anyc)) continue;
+      if (__any(anyc)) {  // (no `continue`: a single loop back-edge keeps the per-pixel state in place, no PHI copies)
       const float4 C = lds_a[j * 4 + 2], Dq = lds_a[j * 4 + 3];  // {r,g,b,rpx} {rpy,nx,ny,nz}
       float4 E0, E1, E2;
       if constexpr (COORD) { E0 = lds_b[j * 3 + 0]; E1 = lds_b[j * 3 + 1]; E2 = lds_b[j * 3 + 2]; }
@@ -606,6 +652,7 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
         for (int s = 0; s < PPL; s++) d = d && (Tw[s] == 0.0f);
         all_done = __all(d);
       }
+      }
     }
   }
 
@@ -614,7 +661,7 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
 #pragma unroll
   for (int s = 0; s < PPL; s++) {
     if (!inside[s]) continue;
-    const size_t pix = (size_t)W * (py0 + 4 * s) + px;
+    const size_t pix = (size_t)W * (py0 + geo.py_step * s) + px;
     const float pny = (pixfy[s] - H / 2.f) / a.focal_y;
     const float ln = sqrtf(pnx * pnx + pny * pny + 1);
     a.n_contrib[pix] = last_c[s];
@@ -984,9 +1031,20 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 bc2(float v) { return f2{v, v}; }
 
-template <bool COORD, bool DEPTH, int PPL>
-__global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 2 : 5))) blend_bwd_packed_kernel(const BlendBwdArgs a) {
+// the row-local part of the butterfly: N components over the 16 lanes of a DPP row.  N = 16: lane l ends with the row total of
+// component l in v[0]; N = 32: with components 2l and 2l+1 in v[0], v[1].
+template <int N>
+__device__ __forceinline__ void row_reduce_scatter(float (&v)[N], int lane) {
+  bfly_stage_dpp<N / 2, 3, 0x128>(v, lane);   // row_ror:8
+  bfly_stage_dpp<N / 4, 2, 0x141>(v, lane);   // row_half_mirror
+  bfly_stage_dpp<N / 8, 1, 0x4E>(v, lane);    // quad_perm [2,3,0,1]
+  bfly_stage_dpp<N / 16, 0, 0xB1>(v, lane);   // quad_perm [1,0,3,2]
+}
+
+template <bool COORD, bool DEPTH, int PPL, bool GROUPED = false>
+__global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 2 : (GROUPED ? 4 : 5)))) blend_bwd_packed_kernel(const BlendBwdArgs a) {
   static_assert(PPL == 2 || PPL == 4, "pairs of pixels per lane");
+  static_assert(!GROUPED || PPL == 2, "grouped streams are built for 2 pixels per lane");
   constexpr bool NORMAL = COORD || DEPTH;
   constexpr int NP = PPL / 2;  // pairs per lane
   constexpr int WPT = 4 / PPL;
@@ -998,14 +1056,14 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
   const int item = xcd_band_remap(blockIdx.x, gridDim.x);
   const int tile = item / WPT, sub = item - tile * WPT;
   const int tile_x = tile % a.gx, tile_y = tile / a.gx;
-  const int lane = threadIdx.x, lx = lane & 15, lr = lane >> 4;
-  const int px = tile_x * 16 + lx;
-  const int py0 = tile_y * 16 + sub * (4 * PPL) + lr;
+  const int lane = threadIdx.x;
+  const GroupGeom geo = lane_geometry<GROUPED, PPL>(lane, tile_x, tile_y, sub);
+  const int px = geo.px;
+  const int py0 = geo.py_first;
   const int W = a.W, H = a.H;
   const size_t HW = (size_t)H * W;
   const float pixfx = (float)px;
-  const float reg_x0 = (float)(tile_x * 16), reg_x1 = reg_x0 + 15.0f;
-  const float reg_y0 = (float)(tile_y * 16 + sub * (4 * PPL)), reg_y1 = reg_y0 + (float)(4 * PPL - 1);
+  const float reg_x0 = geo.rx0, reg_x1 = geo.rx1, reg_y0 = geo.ry0, reg_y1 = geo.ry1;
   const uint2 range = a.ranges[tile];
 
   // Q is the ONE "behind" accumulator per pixel.  Upstream keeps one per blended quantity
@@ -1025,7 +1083,7 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
 #pragma unroll
   for (int s = 0; s < PPL; s++) {
     const int q = s >> 1, e = s & 1;
-    const int py = py0 + 4 * s;
+    const int py = py0 + geo.py_step * s;
     pixfy[q][e] = (float)py;
     const bool inside = px < W && py < H;
     const size_t pix = inside ? (size_t)W * py + px : 0;
@@ -1091,6 +1149,7 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
     __syncthreads();
     const int e0 = hi - 1 - lane;
     bool rel_lane = false;
+    float4 gq0 = make_float4(0.f, 0.f, 0.f, 0.f), gq1 = gq0;
     if (e0 >= 0) {
       const uint32_t g = a.point_list[range.x + e0];
       lds_id[lane] = g;
@@ -1101,13 +1160,18 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
         const float4* sb = a.splat_b + 3 * (size_t)g;
         lds_b[lane * 3 + 0] = sb[0]; lds_b[lane * 3 + 1] = sb[1]; lds_b[lane * 3 + 2] = sb[2];
       }
-      rel_lane = entry_may_touch(q0, q1, reg_x0, reg_x1, reg_y0, reg_y1);
+      if constexpr (GROUPED) { gq0 = q0; gq1 = q1; }
+      else rel_lane = entry_may_touch(q0, q1, reg_x0, reg_x1, reg_y0, reg_y1);
     }
-    uint64_t rel = __ballot(rel_lane);
+    uint64_t rel;
+    int niter = 0;
+    if constexpr (GROUPED) rel = group_masks(e0 >= 0, gq0, gq1, tile_x, tile_y, sub, lane, niter);  // per-row value
+    else { rel = __ballot(rel_lane); niter = (int)__popcll(rel); }
     __syncthreads();
-    while (rel != 0) {
-      const int j = __builtin_ctzll(rel);  // LDS slot j holds list position hi-1-j: ascending j = back to front
-      rel &= rel - 1;
+    for (int it = 0; it < niter; it++) {   // scalar trip count in both variants
+      const bool idle = GROUPED && rel == 0;   // this row's stream is exhausted for the batch
+      const int j = idle ? 0 : __builtin_ctzll(rel);  // LDS slot j holds list position hi-1-j: ascending j = back to front
+      rel &= rel - 1;                                  // 0 stays 0
       const float4 A = lds_a[j * 4 + 0], B = lds_a[j * 4 + 1], C = lds_a[j * 4 + 2], Dq = lds_a[j * 4 + 3];
       const uint32_t gid = lds_id[j];
       const uint32_t pos = (uint32_t)(hi - 1 - j);
@@ -1125,7 +1189,7 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
 #pragma unroll
         for (int e = 0; e < 2; e++) {
           const float pw = power[q][e];
-          cand[2 * q + e] = (pos < last_c[2 * q + e]) && !(pw > 0.0f) && !(pw < B.z);
+          cand[2 * q + e] = !idle && (pos < last_c[2 * q + e]) && !(pw > 0.0f) && !(pw < B.z);
           anyc = anyc || cand[2 * q + e];
         }
       }
@@ -1229,12 +1293,28 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
         gv[14] = fma2(hh, dy[q] * dy[q], gv[14]);
         gv[15] += u;
       }
-      if (!__any(contributed)) continue;
+      const uint64_t contrib_mask = __ballot(contributed);
+      if (contrib_mask == 0) continue;
       float gs[REC];
 #pragma unroll
       for (int i = 0; i < REC; i++) gs[i] = gv[i][0] + gv[i][1];
-      const float tot = wave_reduce_scatter<REC, true>(gs, lane);
-      if (lane < (COORD ? 25 : 16)) unsafeAtomicAdd(a.acc + (size_t)gid * REC + lane, tot);
+      if constexpr (GROUPED) {
+        // every row reduces ITS entry's 16 (32) components over its 16 lanes; rows nobody contributed in skip the update
+        row_reduce_scatter<REC>(gs, lane);
+        const bool row_live = ((contrib_mask >> (lane & 48)) & 0xFFFFull) != 0;
+        const int l = lane & 15;
+        if constexpr (COORD) {
+          if (row_live) {
+            unsafeAtomicAdd(a.acc + (size_t)gid * REC + 2 * l, gs[0]);
+            if (2 * l + 1 < 25) unsafeAtomicAdd(a.acc + (size_t)gid * REC + 2 * l + 1, gs[1]);
+          }
+        } else {
+          if (row_live) unsafeAtomicAdd(a.acc + (size_t)gid * REC + l, gs[0]);
+        }
+      } else {
+        const float tot = wave_reduce_scatter<REC, true>(gs, lane);
+        if (lane < (COORD ? 25 : 16)) unsafeAtomicAdd(a.acc + (size_t)gid * REC + lane, tot);
+      }
     }
   }
 }

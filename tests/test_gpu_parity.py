@@ -205,6 +205,19 @@ def test_pixels_per_lane_variants_agree(fwd_ppl, bwd_ppl, monkeypatch):
     check_backward(s, o, seed=44)
 
 
+@pytest.mark.parametrize("coord,depth", MODES)
+@pytest.mark.parametrize("fwd_grouped,bwd_grouped", [(1, 1), (0, 0)])
+def test_entry_stream_variants_agree(coord, depth, fwd_grouped, bwd_grouped, monkeypatch):
+    """Both blend kernels exist with one culled entry stream per wave and with four (one per 16-lane row, csrc GROUPED); the
+    defaults are forward = one, backward = four.  The other two combinations must pass the same parity checks."""
+    monkeypatch.setenv("RADEGS_GROUPED_FWD", str(fwd_grouped))
+    monkeypatch.setenv("RADEGS_GROUPED_BWD", str(bwd_grouped))
+    s = make_scene(4000, 203, 131, sh_degree=2, mu_px=3.0, seed=61, kernel_size=0.1, require_coord=coord, require_depth=depth, pose="random",
+                   bg=(0.3, 0.1, 0.7))
+    o, _ = check_forward(s)
+    check_backward(s, o, seed=61)
+
+
 def test_forward_is_deterministic_and_backward_stable():
     from gpu_util import HipRun
     s = make_scene(20000, 320, 240, sh_degree=3, mu_px=2.0, seed=8, require_coord=False, require_depth=True)
