@@ -478,39 +478,56 @@ __device__ __forceinline__ int xcd_band_remap(int b, int n) {
 // every iteration: per-lane ctz on a VGPR mask, per-row LDS broadcast reads.  The wave runs max-over-rows iterations
 // (C2: 170 instead of 256).  In the backward the per-Gaussian reduction then IS the row-local part of the butterfly (the four
 // DPP stages, no cross-row exchange) and one 64-lane atomic instruction updates four accumulator lines, one per row.
+// NG = 8 goes one step further: eight 8-lane groups, each owning a 4x4 block (C2: 148 iterations); the reduction is then the
+// three innermost DPP stages and leaves two components per lane (two atomic instructions per iteration).
 struct GroupGeom { int px, py_first, py_step; float rx0, rx1, ry0, ry1; };
-template <bool GROUPED, int PPL>
+template <int NG> struct GroupShape {   // block of one group inside the 16x8 strip
+  static constexpr int LANES = NG ? 64 / NG : 64, BW = NG == 8 ? 4 : 8, BH = 4, COLS = 16 / BW;
+};
+template <int NG, int PPL>
 __device__ __forceinline__ GroupGeom lane_geometry(int lane, int tile_x, int tile_y, int sub) {
   GroupGeom g;
-  if constexpr (GROUPED) {
-    const int grp = lane >> 4, l = lane & 15;
-    const int bx = tile_x * 16 + (grp & 1) * 8, by = tile_y * 16 + sub * 8 + (grp >> 1) * 4;
-    g.px = bx + (l & 7); g.py_first = by + (l >> 3); g.py_step = 2;
-    g.rx0 = (float)bx; g.rx1 = g.rx0 + 7.0f; g.ry0 = (float)by; g.ry1 = g.ry0 + 3.0f;
+  if constexpr (NG != 0) {
+    using S = GroupShape<NG>;
+    const int grp = lane / S::LANES, l = lane % S::LANES;
+    const int bx = tile_x * 16 + (grp % S::COLS) * S::BW, by = tile_y * 16 + sub * 8 + (grp / S::COLS) * S::BH;
+    g.px = bx + (l % S::BW); g.py_first = by + (l / S::BW); g.py_step = 2;
+    g.rx0 = (float)bx; g.rx1 = g.rx0 + (float)(S::BW - 1); g.ry0 = (float)by; g.ry1 = g.ry0 + (float)(S::BH - 1);
   } else {
     g.px = tile_x * 16 + (lane & 15); g.py_first = tile_y * 16 + sub * (4 * PPL) + (lane >> 4); g.py_step = 4;
     g.rx0 = (float)(tile_x * 16); g.rx1 = g.rx0 + 15.0f; g.ry0 = (float)(tile_y * 16 + sub * (4 * PPL)); g.ry1 = g.ry0 + (float)(4 * PPL - 1);
   }
   return g;
 }
-// the batch's survivor mask of this lane's group: lane k holds entry k's record and tests it against all four 8x4 blocks
-// niter (wave-uniform, scalar): the longest of the four streams = the number of iterations the wave runs for this batch
+// The batch's survivor mask of this lane's group: lane k holds entry k's record and tests it against every group's block (the
+// ellipse extents of entry_may_touch are computed once, the per-block part is four compares).  niter (wave-uniform, scalar):
+// the longest of the streams = the number of iterations the wave runs for this batch.
+template <int NG>
 __device__ __forceinline__ uint64_t group_masks(bool valid, const float4 q0, const float4 q1, int tile_x, int tile_y, int sub, int lane,
                                                 int& niter) {
+  using S = GroupShape<NG>;
+  const float mx = q0.x, my = q0.y, cx = q0.z, cy = q0.w, cz = q1.x, thr = q1.z;
+  const float det = cx * cz - cy * cy;
+  const float r = (-2.0f * thr) / det;
+  const float hx = sqrtf(r * cz) * 1.001f + 0.01f, hy = sqrtf(r * cx) * 1.001f + 0.01f;
+  const float xl = mx - hx, xh = mx + hx, yl = my - hy, yh = my + hy;
+  const bool never = thr > 0.0f;
   uint64_t mine = 0;
   niter = 0;
 #pragma unroll
-  for (int grp = 0; grp < 4; grp++) {
-    const float bx = (float)(tile_x * 16 + (grp & 1) * 8), by = (float)(tile_y * 16 + sub * 8 + (grp >> 1) * 4);
-    const uint64_t m = __ballot(valid && entry_may_touch(q0, q1, bx, bx + 7.0f, by, by + 3.0f));
+  for (int grp = 0; grp < NG; grp++) {
+    const float bx = (float)(tile_x * 16 + (grp % S::COLS) * S::BW), by = (float)(tile_y * 16 + sub * 8 + (grp / S::COLS) * S::BH);
+    const bool off = (xh < bx) || (xl > bx + (float)(S::BW - 1)) || (yh < by) || (yl > by + (float)(S::BH - 1)) || never;  // NaN: keep
+    const uint64_t m = __ballot(valid && !off);
     niter = max(niter, (int)__popcll(m));
-    if ((lane >> 4) == grp) mine = m;
+    if (lane / S::LANES == grp) mine = m;
   }
   return mine;
 }
 
-template <bool COORD, bool DEPTH, int PPL, bool GROUPED = false>
+template <bool COORD, bool DEPTH, int PPL, int NG = 0>
 __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
+  constexpr bool GROUPED = NG != 0;
   static_assert(!GROUPED || PPL == 2, "grouped streams are built for 2 pixels per lane");
   constexpr bool NORMAL = COORD || DEPTH;
   constexpr int WPT = 4 / PPL;  // waves per tile
@@ -521,7 +538,7 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
   const int tile = item / WPT, sub = item - tile * WPT;
   const int tile_x = tile % a.gx, tile_y = tile / a.gx;
   const int lane = threadIdx.x;
-  const GroupGeom geo = lane_geometry<GROUPED, PPL>(lane, tile_x, tile_y, sub);
+  const GroupGeom geo = lane_geometry<NG, PPL>(lane, tile_x, tile_y, sub);
   const int px = geo.px;
   const int py0 = geo.py_first;  // slot s -> row py0 + py_step*s
   const int W = a.W, H = a.H;
@@ -581,7 +598,7 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
     }
     uint64_t rel;
     int niter = 0;
-    if constexpr (GROUPED) rel = group_masks(k < n, gq0, gq1, tile_x, tile_y, sub, lane, niter);  // per-lane (per-row) value
+    if constexpr (GROUPED) rel = group_masks<NG>(k < n, gq0, gq1, tile_x, tile_y, sub, lane, niter);  // per-lane (per-group) value
     else { rel = __ballot(rel_lane); niter = (int)__popcll(rel); }
     __syncthreads();
     for (int it = 0; it < niter && !all_done; it++) {   // scalar trip count in both variants
@@ -1033,16 +1050,24 @@ __device__ __forceinline__ f2 bc2(float v) { return f2{v, v}; }
 
 // the row-local part of the butterfly: N components over the 16 lanes of a DPP row.  N = 16: lane l ends with the row total of
 // component l in v[0]; N = 32: with components 2l and 2l+1 in v[0], v[1].
-template <int N>
+// LANES = 16 (N components -> N/16 per lane: lane l holds components l*N/16 ...) or 8 (half rows: N/8 per lane, l = lane & 7).
+template <int N, int LANES>
 __device__ __forceinline__ void row_reduce_scatter(float (&v)[N], int lane) {
-  bfly_stage_dpp<N / 2, 3, 0x128>(v, lane);   // row_ror:8
-  bfly_stage_dpp<N / 4, 2, 0x141>(v, lane);   // row_half_mirror
-  bfly_stage_dpp<N / 8, 1, 0x4E>(v, lane);    // quad_perm [2,3,0,1]
-  bfly_stage_dpp<N / 16, 0, 0xB1>(v, lane);   // quad_perm [1,0,3,2]
+  if constexpr (LANES == 16) {
+    bfly_stage_dpp<N / 2, 3, 0x128>(v, lane);   // row_ror:8
+    bfly_stage_dpp<N / 4, 2, 0x141>(v, lane);   // row_half_mirror
+    bfly_stage_dpp<N / 8, 1, 0x4E>(v, lane);    // quad_perm [2,3,0,1]
+    bfly_stage_dpp<N / 16, 0, 0xB1>(v, lane);   // quad_perm [1,0,3,2]
+  } else {
+    bfly_stage_dpp<N / 2, 2, 0x141>(v, lane);   // row_half_mirror
+    bfly_stage_dpp<N / 4, 1, 0x4E>(v, lane);    // quad_perm [2,3,0,1]
+    bfly_stage_dpp<N / 8, 0, 0xB1>(v, lane);    // quad_perm [1,0,3,2]
+  }
 }
 
-template <bool COORD, bool DEPTH, int PPL, bool GROUPED = false>
-__global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 2 : (GROUPED ? 4 : 5)))) blend_bwd_packed_kernel(const BlendBwdArgs a) {
+template <bool COORD, bool DEPTH, int PPL, int NG = 0>
+__global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 2 : (NG ? 4 : 5)))) blend_bwd_packed_kernel(const BlendBwdArgs a) {
+  constexpr bool GROUPED = NG != 0;
   static_assert(PPL == 2 || PPL == 4, "pairs of pixels per lane");
   static_assert(!GROUPED || PPL == 2, "grouped streams are built for 2 pixels per lane");
   constexpr bool NORMAL = COORD || DEPTH;
@@ -1057,7 +1082,7 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
   const int tile = item / WPT, sub = item - tile * WPT;
   const int tile_x = tile % a.gx, tile_y = tile / a.gx;
   const int lane = threadIdx.x;
-  const GroupGeom geo = lane_geometry<GROUPED, PPL>(lane, tile_x, tile_y, sub);
+  const GroupGeom geo = lane_geometry<NG, PPL>(lane, tile_x, tile_y, sub);
   const int px = geo.px;
   const int py0 = geo.py_first;
   const int W = a.W, H = a.H;
@@ -1165,7 +1190,7 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
     }
     uint64_t rel;
     int niter = 0;
-    if constexpr (GROUPED) rel = group_masks(e0 >= 0, gq0, gq1, tile_x, tile_y, sub, lane, niter);  // per-row value
+    if constexpr (GROUPED) rel = group_masks<NG>(e0 >= 0, gq0, gq1, tile_x, tile_y, sub, lane, niter);  // per-group value
     else { rel = __ballot(rel_lane); niter = (int)__popcll(rel); }
     __syncthreads();
     for (int it = 0; it < niter; it++) {   // scalar trip count in both variants
@@ -1300,16 +1325,14 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
       for (int i = 0; i < REC; i++) gs[i] = gv[i][0] + gv[i][1];
       if constexpr (GROUPED) {
         // every row reduces ITS entry's 16 (32) components over its 16 lanes; rows nobody contributed in skip the update
-        row_reduce_scatter<REC>(gs, lane);
-        const bool row_live = ((contrib_mask >> (lane & 48)) & 0xFFFFull) != 0;
-        const int l = lane & 15;
-        if constexpr (COORD) {
-          if (row_live) {
-            unsafeAtomicAdd(a.acc + (size_t)gid * REC + 2 * l, gs[0]);
-            if (2 * l + 1 < 25) unsafeAtomicAdd(a.acc + (size_t)gid * REC + 2 * l + 1, gs[1]);
-          }
-        } else {
-          if (row_live) unsafeAtomicAdd(a.acc + (size_t)gid * REC + l, gs[0]);
+        constexpr int GL = GroupShape<NG>::LANES, PER = REC / GL;   // components left per lane: comps l*PER .. l*PER+PER-1
+        row_reduce_scatter<REC, GL>(gs, lane);
+        const bool grp_live = ((contrib_mask >> (lane & ~(GL - 1))) & ((1ull << GL) - 1ull)) != 0;
+        const int l = lane & (GL - 1);
+        if (grp_live) {
+#pragma unroll
+          for (int i = 0; i < PER; i++)
+            if (l * PER + i < (COORD ? 25 : 16)) unsafeAtomicAdd(a.acc + (size_t)gid * REC + l * PER + i, gs[i]);
         }
       } else {
         const float tot = wave_reduce_scatter<REC, true>(gs, lane);

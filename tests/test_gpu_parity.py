@@ -206,10 +206,10 @@ def test_pixels_per_lane_variants_agree(fwd_ppl, bwd_ppl, monkeypatch):
 
 
 @pytest.mark.parametrize("coord,depth", MODES)
-@pytest.mark.parametrize("fwd_grouped,bwd_grouped", [(1, 1), (0, 0)])
+@pytest.mark.parametrize("fwd_grouped,bwd_grouped", [(4, 8), (8, 0), (0, 4)])
 def test_entry_stream_variants_agree(coord, depth, fwd_grouped, bwd_grouped, monkeypatch):
-    """Both blend kernels exist with one culled entry stream per wave and with four (one per 16-lane row, csrc GROUPED); the
-    defaults are forward = one, backward = four.  The other two combinations must pass the same parity checks."""
+    """Both blend kernels exist with one culled entry stream per wave (0), four (one per 16-lane row) and eight (one per 8 lanes);
+    every variant must pass the same parity checks, whatever the defaults are."""
     monkeypatch.setenv("RADEGS_GROUPED_FWD", str(fwd_grouped))
     monkeypatch.setenv("RADEGS_GROUPED_BWD", str(bwd_grouped))
     s = make_scene(4000, 203, 131, sh_degree=2, mu_px=3.0, seed=61, kernel_size=0.1, require_coord=coord, require_depth=depth, pose="random",
