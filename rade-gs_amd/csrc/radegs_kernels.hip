@@ -66,6 +66,7 @@ struct PreFwdArgs {
   int write_b;
   int* radii; float4* splat_a; float4* splat_b; uint32_t* tiles_touched; uint32_t* depth_key; uint8_t* clamped;
   float4* inte_rec;  // [P][2] {icr0..icr3 | icr4, icr5, well, 0}; INTE kernel only
+  uint32_t* rect;    // [P] packed tile rectangle
 };
 
 template <bool INTE>
@@ -81,6 +82,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(const PreFwdArgs a)
                  a.colors_precomp ? a.colors_precomp + 3 * (size_t)idx : nullptr, cam, s);
   a.radii[idx] = s.radius;
   a.tiles_touched[idx] = (uint32_t)s.tiles;
+  a.rect[idx] = s.radius > 0 ? s.rect : 0u;
   // positive floats order like unsigned ints; invisible Gaussians sort to the very end
   a.depth_key[idx] = s.radius > 0 ? __float_as_uint(s.depth) : 0xFFFFFFFFu;
   if (s.radius > 0) {
@@ -118,9 +120,12 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* m
 // lane; a splat with many tiles (heavy-overdraw scenes: hundreds per splat) is handed to the whole wave, which writes
 // its instances 64 at a time to consecutive addresses -- coalesced, and no lane serialises a 300-iteration loop.
 constexpr int kEmitCoopThreshold = 16;
+// rect != nullptr (tile grid at most 255x255): the Gaussian's tile rectangle comes packed in ONE random 4-byte gather instead of
+// being recomputed from three (tiles_touched, splat_a, radii).
 __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32_t* idx_sorted, const uint32_t* offsets,
                                                             const uint32_t* tiles_touched, const float4* splat_a, const int* radii,
-                                                            int gx, int gy, uint32_t* tile_keys, uint32_t* vals, uint32_t cap) {
+                                                            const uint32_t* rect, int gx, int gy, uint32_t* tile_keys, uint32_t* vals,
+                                                            uint32_t cap) {
   // cap: capacity of tile_keys/vals.  With exact allocation it equals num_rendered; in the speculative path (rg_launch.inc)
   // it is a prediction and instances beyond it are dropped here (the host detects the overflow and redoes the binning).
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -129,11 +134,18 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32
   int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
   if (i < P) {
     idx = idx_sorted[i];
-    ntiles = tiles_touched[idx];
-    if (ntiles) {
-      off = (i == 0) ? 0u : offsets[i - 1];
-      const float4 a0 = splat_a[4 * (size_t)idx];
-      tile_rect(a0.x, a0.y, radii[idx], gx, gy, x0, y0, x1, y1);
+    if (rect) {
+      const uint32_t r = rect[idx];
+      x0 = (int)(r & 255u); y0 = (int)((r >> 8) & 255u); x1 = x0 + (int)((r >> 16) & 255u); y1 = y0 + (int)(r >> 24);
+      ntiles = (uint32_t)((x1 - x0) * (y1 - y0));
+      if (ntiles) off = (i == 0) ? 0u : offsets[i - 1];
+    } else {
+      ntiles = tiles_touched[idx];
+      if (ntiles) {
+        off = (i == 0) ? 0u : offsets[i - 1];
+        const float4 a0 = splat_a[4 * (size_t)idx];
+        tile_rect(a0.x, a0.y, radii[idx], gx, gy, x0, y0, x1, y1);
+      }
     }
   }
   const bool big = ntiles > (uint32_t)kEmitCoopThreshold;

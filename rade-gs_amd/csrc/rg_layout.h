@@ -47,6 +47,7 @@ struct GeomState {
   uint32_t* tiles_touched; // [P]
   uint32_t* depth_key;     // [P]
   uint8_t* clamped;        // [P]
+  uint32_t* rect;          // [P] packed tile rectangle (x0 | y0<<8 | w<<16 | h<<24): all instance emission needs per Gaussian
   // forward-only scratch
   uint32_t* depth_key_sorted;  // [P]
   uint32_t* idx_sorted;        // [P]
@@ -62,6 +63,7 @@ struct GeomState {
     g.tiles_touched = c.take<uint32_t>(P);
     g.depth_key = c.take<uint32_t>(P);
     g.clamped = c.take<uint8_t>(P);
+    g.rect = c.take<uint32_t>(P);
     g.depth_key_sorted = c.take<uint32_t>(P);
     g.idx_sorted = c.take<uint32_t>(P);
     g.offsets = c.take<uint32_t>(P);

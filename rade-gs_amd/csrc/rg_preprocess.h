@@ -139,6 +139,7 @@ struct SplatFwd {
   float cp[6];          // camera-space coord gradient per pixel (3x2)
   float vp[3];          // view-space mean
   unsigned clamped;     // bit c set <=> channel c was clamped at 0
+  unsigned rect;        // tile rectangle x0 | y0 << 8 | w << 16 | h << 24 (valid when the grid is at most 255x255 tiles)
   // INTE only (the integrate() path): inverse covariance in ray space (u/f, v/f, t), upper triangle, and whether the
   // 3D covariance was well conditioned (computeCov2D<true>, forward.cu:187-235)
   float icr[6];
@@ -185,6 +186,7 @@ RG_HD void preprocess_fwd(v3 p_orig, const float* scale3, const float* quat4, co
   o.radius = 0;
   o.tiles = 0;
   o.clamped = 0;
+  o.rect = 0;
   v3 p_view = xform43(p_orig, cam.view);
   if (p_view.z <= 0.2f) return;  // near cull (auxiliary.h:166); x/y frustum test is disabled upstream
   const float* pm = cam.proj;
@@ -289,6 +291,7 @@ RG_HD void preprocess_fwd(v3 p_orig, const float* scale3, const float* quat4, co
   o.op = opacity * coef;
   o.radius = irad;
   o.tiles = (y1 - y0) * (x1 - x0);
+  o.rect = (unsigned)x0 | ((unsigned)y0 << 8) | ((unsigned)(x1 - x0) << 16) | ((unsigned)(y1 - y0) << 24);
 }
 
 }  // namespace rg

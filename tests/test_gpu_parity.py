@@ -254,6 +254,13 @@ def test_sparse_scene_pixels_without_contributors():
     check_backward(s, o, seed=8, min_strict=0.98)
 
 
+def test_image_wider_than_255_tiles():
+    """gx = 258 tiles: the packed 8-bit tile rectangle of the instance emission does not apply and the rectangle is recomputed."""
+    s = make_scene(3000, 4120, 40, sh_degree=0, mu_px=6.0, seed=17, kernel_size=0.1, require_coord=False, require_depth=True, fovx_deg=100.0)
+    o, _ = check_forward(s)
+    check_backward(s, o, seed=17, min_strict=0.97)
+
+
 def test_handwritten_sort_matches_device_library():
     """The hand-written radix sort / scan (csrc/radegs_sort.hip) against rocPRIM's (RADEGS_PRIMS=rocprim, read once
     per process, hence the subprocess): identical point_list and ranges on a scene big enough for several blocks."""
