@@ -120,8 +120,8 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* m
 // lane; a splat with many tiles (heavy-overdraw scenes: hundreds per splat) is handed to the whole wave, which writes
 // its instances 64 at a time to consecutive addresses -- coalesced, and no lane serialises a 300-iteration loop.
 constexpr int kEmitCoopThreshold = 16;
-// rect != nullptr (tile grid at most 255x255): the Gaussian's tile rectangle comes packed in ONE random 4-byte gather instead of
-// being recomputed from three (tiles_touched, splat_a, radii).
+// rect != nullptr (tile grid at most 255x255): rect[i] is the packed tile rectangle of the i-th Gaussian IN DEPTH ORDER (the scan's
+// gather wrote it): no random access at all here, instead of recomputing the rectangle from three gathers.
 __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32_t* idx_sorted, const uint32_t* offsets,
                                                             const uint32_t* tiles_touched, const float4* splat_a, const int* radii,
                                                             const uint32_t* rect, int gx, int gy, uint32_t* tile_keys, uint32_t* vals,
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32
   if (i < P) {
     idx = idx_sorted[i];
     if (rect) {
-      const uint32_t r = rect[idx];
+      const uint32_t r = rect[i];   // already in depth order (the scan gathered it)
       x0 = (int)(r & 255u); y0 = (int)((r >> 8) & 255u); x1 = x0 + (int)((r >> 16) & 255u); y1 = y0 + (int)(r >> 24);
       ntiles = (uint32_t)((x1 - x0) * (y1 - y0));
       if (ntiles) off = (i == 0) ? 0u : offsets[i - 1];

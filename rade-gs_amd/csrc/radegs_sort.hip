@@ -190,6 +190,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* t
   return off + x - v;
 }
 
+// PACKED: vals hold packed tile rectangles (x0 | y0<<8 | w<<16 | h<<24); the scanned quantity is w*h and `gathered` keeps the raw
+// rectangles in scan order (the instance emission then reads them sequentially).
+__device__ __forceinline__ uint32_t rect_count(uint32_t r) { return ((r >> 16) & 255u) * (r >> 24); }
+
+template <bool PACKED>
 __global__ void __launch_bounds__(kSortThreads) gather_block_sums_kernel(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ idx,
                                                                          uint32_t n, uint32_t* __restrict__ block_sums,
                                                                          uint32_t* __restrict__ gathered) {
@@ -201,7 +206,7 @@ __global__ void __launch_bounds__(kSortThreads) gather_block_sums_kernel(const u
     if (i < n) {
       const uint32_t v = vals[idx ? idx[i] : i];  // the only random gather; the scan pass re-reads it sequentially
       gathered[i] = v;
-      s += v;
+      s += PACKED ? rect_count(v) : v;
     }
   }
   uint32_t total;
@@ -226,6 +231,7 @@ __global__ void __launch_bounds__(kSortThreads) scan_block_sums_kernel(uint32_t*
   }
 }
 
+template <bool PACKED>
 __global__ void __launch_bounds__(kSortThreads) gather_scan_kernel(const uint32_t* __restrict__ gathered, uint32_t n,
                                                                    const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ out) {
   const uint32_t base = blockIdx.x * (uint32_t)(kSortThreads * kScanItems) + threadIdx.x * kScanItems;
@@ -234,7 +240,7 @@ __global__ void __launch_bounds__(kSortThreads) gather_scan_kernel(const uint32_
 #pragma unroll
   for (int k = 0; k < kScanItems; k++) {
     const uint32_t i = base + k;
-    v[k] = i < n ? gathered[i] : 0u;
+    v[k] = i < n ? (PACKED ? rect_count(gathered[i]) : gathered[i]) : 0u;
     s += v[k];
   }
   uint32_t run = block_sums[blockIdx.x] + block_exclusive_scan(s, nullptr);
@@ -310,16 +316,20 @@ size_t scan_temp_bytes(size_t n) {
 }
 
 // out[i] = sum_{j <= i} vals[idx[j]]   (rasterizer_impl.cu:350's InclusiveSum, taken in depth order); idx == nullptr: identity
+// packed_out != nullptr: `vals` are packed tile rectangles, the scan runs over their tile counts and packed_out[i] receives
+// vals[idx[i]] (n words).
 hipError_t inclusive_scan_gather_u32(void* temp, size_t temp_bytes, const uint32_t* vals, const uint32_t* idx, uint32_t* out, size_t n,
-                                     hipStream_t stream) {
+                                     hipStream_t stream, uint32_t* packed_out) {
   if (n == 0) return hipSuccess;
   if (temp_bytes < scan_temp_bytes(n)) return hipErrorInvalidValue;
   const uint32_t nblocks = (uint32_t)((n + kSortThreads * kScanItems - 1) / (kSortThreads * kScanItems));
   uint32_t* block_sums = static_cast<uint32_t*>(temp);
-  uint32_t* gathered = block_sums + ((nblocks + 64) & ~63u);
-  hipLaunchKernelGGL(gather_block_sums_kernel, dim3(nblocks), dim3(kSortThreads), 0, stream, vals, idx, (uint32_t)n, block_sums, gathered);
+  uint32_t* gathered = packed_out ? packed_out : block_sums + ((nblocks + 64) & ~63u);
+  if (packed_out) hipLaunchKernelGGL(gather_block_sums_kernel<true>, dim3(nblocks), dim3(kSortThreads), 0, stream, vals, idx, (uint32_t)n, block_sums, gathered);
+  else hipLaunchKernelGGL(gather_block_sums_kernel<false>, dim3(nblocks), dim3(kSortThreads), 0, stream, vals, idx, (uint32_t)n, block_sums, gathered);
   hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(kSortThreads), 0, stream, block_sums, nblocks);
-  hipLaunchKernelGGL(gather_scan_kernel, dim3(nblocks), dim3(kSortThreads), 0, stream, gathered, (uint32_t)n, block_sums, out);
+  if (packed_out) hipLaunchKernelGGL(gather_scan_kernel<true>, dim3(nblocks), dim3(kSortThreads), 0, stream, gathered, (uint32_t)n, block_sums, out);
+  else hipLaunchKernelGGL(gather_scan_kernel<false>, dim3(nblocks), dim3(kSortThreads), 0, stream, gathered, (uint32_t)n, block_sums, out);
   return hipGetLastError();
 }
 }  // namespace rg

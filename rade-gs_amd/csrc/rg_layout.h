@@ -52,6 +52,7 @@ struct GeomState {
   uint32_t* depth_key_sorted;  // [P]
   uint32_t* idx_sorted;        // [P]
   uint32_t* offsets;           // [P] inclusive scan of tiles_touched in depth order
+  uint32_t* rect_sorted;       // [P] packed tile rectangles in depth order (written by the scan's gather, read by the emission)
   char* temp;                  // device-primitive temp storage
   size_t temp_bytes;
   size_t total;
@@ -67,6 +68,7 @@ struct GeomState {
     g.depth_key_sorted = c.take<uint32_t>(P);
     g.idx_sorted = c.take<uint32_t>(P);
     g.offsets = c.take<uint32_t>(P);
+    g.rect_sorted = c.take<uint32_t>(P);
     g.temp = c.take<char>(temp_bytes);
     g.temp_bytes = temp_bytes;
     g.total = c.total();
