@@ -43,6 +43,7 @@ void hc_preprocess_fwd(int P, int deg, int M, const float* means, const float* s
     for (int k = 0; k < 6; k++) f[15 + k] = s.cp[k];
     for (int k = 0; k < 3; k++) f[21 + k] = s.vp[k];
     f[24] = s.depth; f[25] = 0; f[26] = 0;
+    memcpy(&f[25], &s.rect, 4);   // packed tile rectangle, bit pattern carried in a float slot
     out_i[3 * i] = s.radius; out_i[3 * i + 1] = s.tiles; out_i[3 * i + 2] = (int)s.clamped;
   }
 }

@@ -57,6 +57,15 @@ def test_preprocess_forward_and_backward_bit_exact(case):
              "view_points": (o.get("view_points", (P, 3)), f[:, 21:24]), "depths": (o.get("depths"), f[:, 24])}
     for k, (a, b) in pairs.items():
         assert np.array_equal(bits(a[vis]), bits(b[vis])), k
+    # the packed tile rectangle the instance emission consumes: w*h = tiles touched, origin = getRect() of the oracle's mean/radius
+    rect = np.ascontiguousarray(f[:, 25]).view(np.uint32)
+    x0, y0, w, h = rect & 255, (rect >> 8) & 255, (rect >> 16) & 255, rect >> 24
+    assert np.array_equal((w * h)[vis], o.get("tiles_touched")[vis])
+    m2 = o.get("means2D", (P, 2))
+    gx, gy = (s.W + 15) // 16, (s.H + 15) // 16
+    ex0 = np.clip(((m2[:, 0] - radii) / 16).astype(np.int64), 0, gx)          # auxiliary.h getRect: (int) truncation, then clamp
+    ey0 = np.clip(((m2[:, 1] - radii) / 16).astype(np.int64), 0, gy)
+    assert np.array_equal(x0[vis], ex0[vis]) and np.array_equal(y0[vis], ey0[vis])
     cl = o.get("clamped").reshape(P, 3)
     clb = (cl[:, 0] + 2 * cl[:, 1] + 4 * cl[:, 2]).astype(np.int32)
     assert np.array_equal(clb[vis], i[vis, 2])
