@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C2", help="BASELINE.json config (C1..C5); the headline metric is quoted on C2")
     ap.add_argument("--points", type=int, default=0, help="override the number of Gaussians (debug only)")
+    ap.add_argument("--mu-px", type=float, default=0.0, help="override the median splat size in pixels (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-allreduce", action="store_true", help="run the RCCL gradient exchange even at world size 1 (path check)")
     ap.add_argument("--exchange", choices=("factored", "allreduce"), default="factored",
@@ -89,6 +90,8 @@ def main():
     over = {}
     if args.points:
         over["P"] = args.points
+    if args.mu_px:
+        over["mu_px"] = args.mu_px
     cfg = dict(CONFIGS[args.config])
     scene_cpu = make_config(args.config, **over)
     if world > 1:  # the SAME Gaussians on every rank, each rank renders its own neighbouring view of them (rank 0: the config's view)
