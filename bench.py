@@ -171,11 +171,11 @@ def main():
         ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in stages.items()}
         grouped = {"preprocess_fwd": ms["preprocess_fwd"],
                    "binning": ms["sort_depth"] + ms["scan"] + ms["emit_instances"] + ms["sort_tile"] + ms["tile_ranges"],
-                   "blend_fwd": ms["blend_fwd"], "blend_bwd": ms["blend_bwd"] + ms["acc_zero"], "preprocess_bwd": ms["preprocess_bwd"]}
+                   "blend_fwd": ms["blend_fwd"] + ms.get("block_lists", 0.0), "blend_bwd": ms["blend_bwd"] + ms["acc_zero"], "preprocess_bwd": ms["preprocess_bwd"]}
         dom_ms = ms[dom]
         achieved = ab[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         gpu_ms = sum(grouped.values())
-        kernel_name = {"blend_bwd": "blend_bwd_packed_kernel"}.get(dom, dom + "_kernel")
+        kernel_name = {"blend_bwd": "blend_bwd_"}.get(dom, dom + "_")   # prefix of the kernel's name in the rocprof summaries
         traffic, traffic_note = pmc_traffic(kernel_name, args.config, P, W, H)
         out = {
             "metric": "fwd+bwd Msplats/s @1080p, 1M Gaussians; depth L1 vs ref", "value": round(value, 2), "unit": "Msplats/s",

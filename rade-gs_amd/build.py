@@ -24,7 +24,7 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
 UNITS = {
     "radegs_prims": ["radegs_prims.hip", "rg_prims.h"],
     "radegs_sort": ["radegs_sort.hip", "rg_prims.h"],
-    "radegs_kernels": ["radegs_kernels.hip", "rg_launch.inc", "rg_math.h", "rg_blend.h", "rg_preprocess.h", "rg_preprocess_bwd.h",
+    "radegs_kernels": ["radegs_kernels.hip", "rg_launch.inc", "rg_streams.inc", "rg_math.h", "rg_blend.h", "rg_preprocess.h", "rg_preprocess_bwd.h",
                        "rg_layout.h", "rg_prims.h", os.path.join("..", "..", "include", "radegs.h")],
     "radegs_normals": ["radegs_normals.hip", os.path.join("..", "..", "include", "radegs.h")],
     "radegs_filter3d": ["radegs_filter3d.hip", os.path.join("..", "..", "include", "radegs.h")],

@@ -474,6 +474,7 @@ struct BlendFwdArgs {
   const float* bg;
   float* out_color; float* out_coord; float* out_mcoord; float* out_depth; float* out_mdepth; float* out_alpha; float* out_normal;
   uint32_t* n_contrib; float* accum_coord; float* accum_depth; float* normal_length;
+  const uint32_t* blk_count; uint32_t* blk_consumed; uint32_t* blk_chunks;   // sub-tile entry streams (rg_streams.inc)
 };
 
 // blockIdx -> work item such that each XCD (block b runs on XCD b % 8) owns a contiguous band.
@@ -747,6 +748,7 @@ struct BlendBwdArgs {
   const float* dL_dpix; const float* dL_dcoord; const float* dL_dmcoord; const float* dL_ddepth; const float* dL_dmdepth;
   const float* dL_dalpha; const float* dL_dnormal;
   float* acc;  // [P][REC] per-Gaussian sums, SplatAcc order
+  const uint32_t* blk_consumed; const uint32_t* blk_chunks;   // sub-tile entry streams (rg_streams.inc)
 };
 
 // In: v[i] = this lane's partial sum of component i.  Out (return value): the wave-wide total of
@@ -1522,6 +1524,9 @@ __global__ void __launch_bounds__(kPreBwdThreads) sh_grad_from_views_kernel(int 
 }
 
 }  // namespace rg
+
+// The blend kernels over sub-tile entry streams use the helpers above.
+#include "rg_streams.inc"
 
 // The host-side orchestration and the C ABI (include/radegs.h) follow; they need the kernels above in scope.
 #include "rg_launch.inc"

@@ -98,14 +98,30 @@ struct BinState {
   }
 };
 
+// Sub-tile entry streams (rg_streams.inc): every 16x16 tile is split into 8 blocks of 8x4 pixels and every block gets its
+// own exactly culled, depth-ordered sub-list of the tile's list.  Storage is an array of ROUND CHUNKS: one chunk = the 16
+// entries a block's 16 lanes stage at a time = 16 x {gaussian id, position in the tile list} followed by the 16 per-lane
+// contribution words the forward blend leaves for the backward (bit j / 16+j: the lane's first / second pixel blended
+// entry j of this round).  The chunks of (tile t, block b) start at chunk index
+//     8 * ((range.x[t] >> 4) + t) + b * ceil(n_t / 16)
+// which needs no counting pass: sum_{t' < t} ceil(n_t'/16) <= (range.x[t] >> 4) + t.
+constexpr int kBlocksPerTile = 8;
+constexpr int kChunkWords = 48;   // 16 x uint2 + 16 x u32
+inline size_t stream_chunk_capacity(size_t R, size_t tiles) { return (size_t)kBlocksPerTile * ((R >> 4) + tiles + 1); }
+
 struct ImageState {
   uint32_t* ranges;      // [2*tiles]  (start,end) per tile
   uint32_t* n_contrib;   // [2*H*W]    plane 0: last contributor, plane 1: last contributor with T>0.5
   float* accum_coord;    // [3*H*W]
   float* accum_depth;    // [H*W]
   float* normal_length;  // [H*W]
+  // entry streams (only when stream_R != 0).  They live at the END of the image state so that every offset above and the
+  // bases below depend on (W, H) alone: the backward finds them without knowing the capacity the forward allocated for.
+  uint32_t* blk_count;     // [8*tiles] entries in each block's list
+  uint32_t* blk_consumed;  // [8*tiles] entries of it the forward walked before all of the block's pixels had terminated
+  uint32_t* blk_chunks;    // [stream_chunk_capacity(stream_R, tiles) * kChunkWords]
   size_t total;
-  static ImageState carve(void* buf, size_t W, size_t H) {
+  static ImageState carve(void* buf, size_t W, size_t H, size_t stream_R = 0) {
     Carver c(buf);
     ImageState s;
     const size_t tiles = ((W + 15) / 16) * ((H + 15) / 16), N = W * H;
@@ -114,6 +130,9 @@ struct ImageState {
     s.accum_coord = c.take<float>(3 * N);
     s.accum_depth = c.take<float>(N);
     s.normal_length = c.take<float>(N);
+    s.blk_count = c.take<uint32_t>(kBlocksPerTile * tiles);
+    s.blk_consumed = c.take<uint32_t>(kBlocksPerTile * tiles);
+    s.blk_chunks = c.take<uint32_t>(stream_R ? stream_chunk_capacity(stream_R, tiles) * kChunkWords : 0);
     s.total = c.total();
     return s;
   }

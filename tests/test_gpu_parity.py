@@ -198,6 +198,7 @@ def test_mark_visible():
 
 @pytest.mark.parametrize("fwd_ppl,bwd_ppl", [(1, 2), (2, 4), (4, 2)])
 def test_pixels_per_lane_variants_agree(fwd_ppl, bwd_ppl, monkeypatch):
+    monkeypatch.setenv("RADEGS_STREAMS", "0")   # these are variants of the tile-wide kernels
     monkeypatch.setenv("RADEGS_FWD_PPL", str(fwd_ppl))
     monkeypatch.setenv("RADEGS_BWD_PPL", str(bwd_ppl))
     s = make_scene(3000, 200, 136, sh_degree=3, mu_px=4.0, seed=44, kernel_size=0.1, require_coord=True, require_depth=True, pose="random")
@@ -210,12 +211,49 @@ def test_pixels_per_lane_variants_agree(fwd_ppl, bwd_ppl, monkeypatch):
 def test_entry_stream_variants_agree(coord, depth, fwd_grouped, bwd_grouped, monkeypatch):
     """Both blend kernels exist with one culled entry stream per wave (0), four (one per 16-lane row) and eight (one per 8 lanes);
     every variant must pass the same parity checks, whatever the defaults are."""
+    monkeypatch.setenv("RADEGS_STREAMS", "0")   # these are variants of the tile-wide kernels
     monkeypatch.setenv("RADEGS_GROUPED_FWD", str(fwd_grouped))
     monkeypatch.setenv("RADEGS_GROUPED_BWD", str(bwd_grouped))
     s = make_scene(4000, 203, 131, sh_degree=2, mu_px=3.0, seed=61, kernel_size=0.1, require_coord=coord, require_depth=depth, pose="random",
                    bg=(0.3, 0.1, 0.7))
     o, _ = check_forward(s)
     check_backward(s, o, seed=61)
+
+
+@pytest.mark.parametrize("coord,depth", MODES)
+@pytest.mark.parametrize("streams", [0, 1])
+def test_blend_paths_agree_with_oracle(coord, depth, streams, monkeypatch):
+    """The blend stage exists twice: tile-wide kernels (one wave per strip walks the tile's list) and sub-tile entry streams
+    (csrc/rg_streams.inc: exactly culled per-block lists, the backward replays the forward's contribution bits).  The launcher
+    picks by splat size; both must pass the same parity checks on the same scene whatever the default is."""
+    monkeypatch.setenv("RADEGS_STREAMS", str(streams))
+    s = make_scene(6000, 203, 131, sh_degree=2, mu_px=2.0, seed=62, kernel_size=0.1, require_coord=coord, require_depth=depth, pose="random",
+                   bg=(0.3, 0.1, 0.7))
+    o, _ = check_forward(s)
+    check_backward(s, o, seed=62)
+
+
+def test_entry_streams_heavy_overdraw_termination_and_ragged_image(monkeypatch):
+    """Forced entry streams on big splats: lists of hundreds of entries per block, rows of pixels that terminate early (their
+    block stops consuming its list) next to rows that do not, partial rounds, tail tiles of a ragged image."""
+    monkeypatch.setenv("RADEGS_STREAMS", "1")
+    s = make_scene(6000, 203, 117, sh_degree=2, mu_px=14.0, seed=33, kernel_size=0.0, require_coord=True, require_depth=True,
+                   pose="identity")
+    o, _ = check_forward(s)
+    check_backward(s, o, seed=33)
+    s = make_scene(4000, 320, 200, sh_degree=1, mu_px=1.5, seed=3, kernel_size=0.0, require_coord=False, require_depth=True)   # sparse
+    o, _ = check_forward(s)
+    check_backward(s, o, seed=3)
+
+
+def test_tile_wide_backward_after_stream_forward(monkeypatch):
+    """The tile-wide backward only needs the tile lists and n_contrib, so it is the fallback whenever the image state's entry
+    streams cannot be trusted (e.g. the buffer was copied): it must accept the state a stream forward left."""
+    monkeypatch.setenv("RADEGS_STREAMS", "1")
+    monkeypatch.setenv("RADEGS_STREAMS_BWD", "0")
+    s = make_scene(5000, 200, 136, sh_degree=1, mu_px=2.0, seed=64, kernel_size=0.1, require_coord=False, require_depth=True, pose="random")
+    o, _ = check_forward(s)
+    check_backward(s, o, seed=64)
 
 
 def test_forward_is_deterministic_and_backward_stable():
