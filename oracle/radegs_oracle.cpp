@@ -127,14 +127,14 @@ template <class R> inline V3<R> dnormvdv(const V3<R>& v, const V3<R>& dv) {
 template <class R> inline R ndc_to_pix(R v, int S) {
   return static_cast<R>(((static_cast<double>(v) + 1.0) * S - 1.0) * 0.5);
 }
-// getRect, auxiliary.h:62-72
+// getRect, auxiliary.h:62-72 (upper bound in the reference's left-to-right float order: ((p + r) + BLOCK) - 1)
 template <class R>
 inline void tile_rect(R px, R py, int max_radius, int gx, int gy, uint32_t rmin[2], uint32_t rmax[2]) {
   const R rad = static_cast<R>(max_radius);
   rmin[0] = std::min<int64_t>(gx, std::max(0, to_int_sat((px - rad) / R(TILE))));
   rmin[1] = std::min<int64_t>(gy, std::max(0, to_int_sat((py - rad) / R(TILE))));
-  rmax[0] = std::min<int64_t>(gx, std::max(0, to_int_sat((px + rad + R(TILE - 1)) / R(TILE))));
-  rmax[1] = std::min<int64_t>(gy, std::max(0, to_int_sat((py + rad + R(TILE - 1)) / R(TILE))));
+  rmax[0] = std::min<int64_t>(gx, std::max(0, to_int_sat((((px + rad) + R(TILE)) - R(1)) / R(TILE))));
+  rmax[1] = std::min<int64_t>(gy, std::max(0, to_int_sat((((py + rad) + R(TILE)) - R(1)) / R(TILE))));
 }
 
 // Shared geometry recomputation used by forward computeCov2D (forward.cu:77-264) and by

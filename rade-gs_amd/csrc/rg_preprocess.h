@@ -41,13 +41,14 @@ struct Camera {
 // ((v+1)*S-1)/2 evaluated in double, rounded once to float (auxiliary.h:57-60)
 RG_HD float ndc_to_pix(float v, int S) { return (float)((((double)v + 1.0) * S - 1.0) * 0.5); }
 
-// Tile rectangle of a splat (auxiliary.h:62-72).
+// Tile rectangle of a splat (auxiliary.h:62-72).  The upper bound is spelled as the reference evaluates it in float, left to
+// right: ((p + r) + BLOCK) - 1 -- a single "+ 15" can round differently by one ulp and move a tile boundary.
 RG_HD void tile_rect(float px, float py, int max_radius, int gx, int gy, int& x0, int& y0, int& x1, int& y1) {
   const float rad = (float)max_radius;
   x0 = imin(gx, imax(0, f2i_sat((px - rad) / (float)kTile)));
   y0 = imin(gy, imax(0, f2i_sat((py - rad) / (float)kTile)));
-  x1 = imin(gx, imax(0, f2i_sat((px + rad + (float)(kTile - 1)) / (float)kTile)));
-  y1 = imin(gy, imax(0, f2i_sat((py + rad + (float)(kTile - 1)) / (float)kTile)));
+  x1 = imin(gx, imax(0, f2i_sat((((px + rad) + (float)kTile) - 1.0f) / (float)kTile)));
+  y1 = imin(gy, imax(0, f2i_sat((((py + rad) + (float)kTile) - 1.0f) / (float)kTile)));
 }
 
 // Sigma = (S R)^T (S R) from scale and the UN-normalised quaternion (r,x,y,z); 6 unique entries.

@@ -317,12 +317,20 @@ def test_handwritten_sort_matches_device_library():
         "print('HASH', st[0], hashlib.sha1(pl.tobytes() + rg.tobytes()).hexdigest())\n"
     ) % tuple(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), p) for p in ("", "rade-gs_amd", "tests"))
     outs = []
-    for prims in ("", "rocprim"):
-        env = dict(os.environ, RADEGS_PRIMS=prims)
+    for over in (dict(), dict(RADEGS_PRIMS="rocprim")):
+        env = dict(os.environ, **over)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][0])
     assert outs[0] == outs[1], outs
+
+
+def test_very_long_tile_lists():
+    """Every Gaussian covers the whole 48x32 image, so each of the 6 tiles lists all 9000 of them (hundreds of staging rounds per
+    block, every block list as long as the tile list), twice in a row (exact sizes, then the speculative capacity)."""
+    s = make_scene(9000, 48, 32, sh_degree=0, mu_px=60.0, seed=91, kernel_size=0.0, require_coord=False, require_depth=True, low_opacity=True)
+    check_forward(s)
+    check_forward(s)
 
 
 def test_speculative_binning_matches_exact_path():
