@@ -31,16 +31,33 @@ _SPEC = os.environ.get("RADEGS_FUZZ_SEEDS", "0:14")
 _SEEDS = [int(v) for v in _SPEC.split(",")] if "," in _SPEC else list(range(*(int(v) for v in _SPEC.split(":"))))
 
 
-@pytest.mark.parametrize("seed", _SEEDS)
-def test_random_configuration(seed):
+# Gradient criteria of the sweep (check_backward): >= 97 % of every tensor's elements inside the strict 1e-5 / 1e-4 bar, the rest
+# inside 4x the fp32 noise band; against the fp64 oracle at most 1.5x the fp32 oracle's own rms error and 2x its max error.  The
+# standard scenes of test_gpu_parity.py use 0.99 / 1x / 1.1 / 1.25; scenes of a few hundred Gaussians make those statistics noisy
+# (the fp32 oracle's own error is ONE random draw of rounding, the HIP path's another), which is all the widening covers: 40 seeds
+# pass these bounds in either blend path, 35 of 40 pass the standard ones (RADEGS_FUZZ_THRESH overrides for such experiments).
+_THRESH = [float(v) for v in os.environ.get("RADEGS_FUZZ_THRESH", "0.97,1.5,2.0,4.0").split(",")]
+
+
+def _run(seed):
     kw, scale_modifier = _config(seed)
     if kw["mu_px"] >= 12.0:
         kw["P"] = min(kw["P"], 2500)  # heavy overdraw: keep the oracle's backward in seconds
     s = make_scene(**kw)
     o, h = check_forward(s, scale_modifier=scale_modifier)
-    # Scenes of a few hundred Gaussians make the statistical criteria noisy (the fp32-oracle's own error is one random draw of
-    # rounding, the HIP path's another): the strict-fraction floor and the fp64-arbiter factors are widened accordingly.  What
-    # the sweep is for -- NaNs, wrong indices, gross errors on odd shapes/modes -- is untouched by this.  (More entry streams per
-    # wave also mean more, smaller fp32 partial sums per Gaussian: the forced 8-stream backward sits at ~2x the oracle's rms error
-    # on 300-Gaussian scenes; the reference itself adds one atomic per pixel-Gaussian pair.)
-    check_backward(s, o, seed=seed, min_strict=0.90, scale_modifier=scale_modifier, rms_factor=2.5, max_factor=5.0, band_factor=16.0)
+    check_backward(s, o, seed=seed, min_strict=_THRESH[0], scale_modifier=scale_modifier, rms_factor=_THRESH[1], max_factor=_THRESH[2],
+                   band_factor=_THRESH[3])
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
+def test_random_configuration(seed):
+    _run(seed)
+
+
+@pytest.mark.parametrize("streams", [0, 1])
+@pytest.mark.parametrize("seed", [14, 15, 16, 17, 18, 19])
+def test_random_configuration_forced_blend_path(seed, streams, monkeypatch):
+    """The launcher picks tile-wide kernels or sub-tile entry streams by splat size; here each is forced on scenes it would not
+    have been picked for (big splats through the streams, tiny ones through the tile-wide walk)."""
+    monkeypatch.setenv("RADEGS_STREAMS", str(streams))
+    _run(seed)
