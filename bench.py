@@ -106,7 +106,7 @@ def main():
             bucket = FactoredGradExchange(P, s.shs.shape[1], s.sh_degree, dev)
         else:
             bucket = GradBucket(P, s.shs.shape[1], dev)
-        C.GRAD_ALLOCATOR = bucket.allocator
+        C.set_grad_allocator(dev, bucket.allocator)
 
     def step():
         fw = C.rasterize_gaussians(s.bg, s.means3D, e, s.opacities, s.scales, s.rotations, 1.0, e, s.viewmatrix, s.projmatrix, s.tanfovx,

@@ -79,8 +79,14 @@ typedef struct RadegsFwdArgs {
   int* radii;                   /* [P] */
 } RadegsFwdArgs;
 
-/* Returns num_rendered (>= 0) or a negative RADEGS_ERR_*.  Synchronises the stream once (the
- * 4-byte read-back of num_rendered that sizes the binning buffer, like rasterizer_impl.cu:354). */
+/* Returns num_rendered (>= 0) or a negative RADEGS_ERR_*.
+ * Host synchronisation: the FIRST call for a (device, width, height) waits for num_rendered in the middle of the forward to
+ * size the binning buffer, like rasterizer_impl.cu:354.  Later calls allocate for a capacity predicted from the previous
+ * counts, queue the whole forward, and wait only for the 4-byte count at the very end (an event, not a stream sync); a too
+ * small prediction is detected there and the forward is redone with exact sizes.  RADEGS_SPECULATE=0 restores the first
+ * behaviour for every call.  The allocators may therefore be asked for MORE than the exact state size, and -- on a redo --
+ * a second time within one call.  The image-state callback is invoked after the capacity is known (its tail holds the
+ * sub-tile entry streams of the blend stage when the scene's splats are small). */
 int radegs_forward(const RadegsFwdArgs* args, radegs_alloc_fn geom_alloc, void* geom_user, radegs_alloc_fn binning_alloc,
                    void* binning_user, radegs_alloc_fn image_alloc, void* image_user, void* stream);
 

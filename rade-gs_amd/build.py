@@ -18,11 +18,12 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "diff_gaussian_rasterization")
 OBJ_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(OUT_DIR, "libradegs_hip.so")
+CHECK_LIB = os.path.join(OUT_DIR, "libradegs_prims_check.so")   # test-only: rocPRIM cross-check of the hand-written sorts
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-Wno-unused-value", "-I", CSRC]
 UNITS = {
-    "radegs_prims": ["radegs_prims.hip", "rg_prims.h"],
+    "radegs_prims": ["radegs_prims.hip"],
     "radegs_sort": ["radegs_sort.hip", "rg_prims.h"],
     "radegs_kernels": ["radegs_kernels.hip", "rg_launch.inc", "rg_streams.inc", "rg_math.h", "rg_blend.h", "rg_preprocess.h", "rg_preprocess_bwd.h",
                        "rg_layout.h", "rg_prims.h", os.path.join("..", "..", "include", "radegs.h")],
@@ -56,8 +57,15 @@ def build(force=False, verbose=True):
             if verbose:
                 print("[radegs build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+        if name == "radegs_prims":   # never linked into the product: its own shared object, loaded on demand (RADEGS_PRIMS=rocprim)
+            if force or _stale(CHECK_LIB, [obj]):
+                cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", CHECK_LIB, obj]
+                if verbose:
+                    print("[radegs build]", " ".join(cmd), flush=True)
+                subprocess.check_call(cmd)
+            continue
         objs.append(obj)
-    if force or _stale(LIB, objs):
+    if force or _stale(LIB, objs + [os.path.abspath(__file__)]):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print("[radegs build]", " ".join(cmd), flush=True)

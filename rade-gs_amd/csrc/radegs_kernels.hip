@@ -204,8 +204,11 @@ __device__ __forceinline__ bool entry_may_touch(const float4 q0, const float4 q1
   const float r = m / det;
   const float hx = sqrtf(r * cz) * 1.001f + 0.01f;
   const float hy = sqrtf(r * cx) * 1.001f + 0.01f;
-  const bool off = (mx + hx < x_lo) || (mx - hx > x_hi) || (my + hy < y_lo) || (my - hy > y_hi) || (thr > 0.0f);
-  return !off;
+  const bool off = (mx + hx < x_lo) || (mx - hx > x_hi) || (my + hy < y_lo) || (my - hy > y_hi);
+  // The extents only mean something for a positive-definite conic.  A needle-thin splat's determinant can round to <= 0 (the
+  // preprocess only rejects det == 0, forward.cu:127): such an entry is kept and the exact per-pixel rule decides, as for NaN.
+  const bool definite = (det > 0.0f) && (cx > 0.0f) && (cz > 0.0f);
+  return !(thr > 0.0f) && !(off && definite);
 }
 
 __device__ __forceinline__ int xcd_band_remap(int b, int n);
@@ -525,13 +528,14 @@ __device__ __forceinline__ uint64_t group_masks(bool valid, const float4 q0, con
   const float hx = sqrtf(r * cz) * 1.001f + 0.01f, hy = sqrtf(r * cx) * 1.001f + 0.01f;
   const float xl = mx - hx, xh = mx + hx, yl = my - hy, yh = my + hy;
   const bool never = thr > 0.0f;
+  const bool definite = (det > 0.0f) && (cx > 0.0f) && (cz > 0.0f);   // otherwise the extents are meaningless: keep (see entry_may_touch)
   uint64_t mine = 0;
   niter = 0;
 #pragma unroll
   for (int grp = 0; grp < NG; grp++) {
     const float bx = (float)(tile_x * 16 + (grp % S::COLS) * S::BW), by = (float)(tile_y * 16 + sub * 8 + (grp / S::COLS) * S::BH);
-    const bool off = (xh < bx) || (xl > bx + (float)(S::BW - 1)) || (yh < by) || (yl > by + (float)(S::BH - 1)) || never;  // NaN: keep
-    const uint64_t m = __ballot(valid && !off);
+    const bool off = ((xh < bx) || (xl > bx + (float)(S::BW - 1)) || (yh < by) || (yl > by + (float)(S::BH - 1))) && definite;  // NaN: keep
+    const uint64_t m = __ballot(valid && !off && !never);
     niter = max(niter, (int)__popcll(m));
     if (lane / S::LANES == grp) mine = m;
   }

@@ -14,6 +14,7 @@ There is NO CPU path and no fallback: a missing library or a non-GPU tensor rais
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -92,7 +93,31 @@ LAST_POINT_STATE = None
 # Optional allocator for the 8 gradient tensors of the backward: callable(name, shape, dtype, device) -> tensor
 # or None.  A data-parallel caller points it at slices of ONE flat bucket so that the gradient all-reduce needs no
 # gather copy (rade-gs_amd/view_parallel.GradBucket).  Default: plain torch.empty.
+# Installed PER DEVICE with set_grad_allocator(device, fn): autograd runs every device's backward on its own worker thread,
+# so one process driving several GPUs must not share a single hook.  The module attribute GRAD_ALLOCATOR is the fallback for
+# devices without their own entry (one process per GPU, the deployment this library is built for, needs nothing else).
 GRAD_ALLOCATOR = None
+_GRAD_ALLOCATORS = {}
+_HOOK_LOCK = threading.Lock()
+
+
+def set_grad_allocator(device, fn):
+    """Install (fn) or remove (None) the gradient allocator of one device; see GRAD_ALLOCATOR."""
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    with _HOOK_LOCK:
+        if fn is None:
+            _GRAD_ALLOCATORS.pop(idx, None)
+        else:
+            _GRAD_ALLOCATORS[idx] = fn
+
+
+def _grad_allocator_for(dev):
+    with _HOOK_LOCK:
+        return _GRAD_ALLOCATORS.get(dev.index, GRAD_ALLOCATOR)
+
+
 # The allocator may also (a) return a (P,3) tensor for the extra name "dL_drgb_clamped" -- the backward then fills it with
 # dL/dRGB (clamp mask applied) -- and (b) return SKIP_GRAD for "dL_dsh": the (P,M,3) SH gradient is then not written and
 # comes back as None (it is basis(dir) x dL_drgb_clamped; view_parallel.FactoredGradExchange rebuilds the batch sum).
@@ -186,6 +211,11 @@ class _Resizable:
 
         self.cb = _ALLOC_FN(_cb)
 
+    def release(self):
+        """Drop the ctypes callback once the native call has returned: it closes over `self`, and the cycle would keep the
+        tensor (hundreds of MB of device memory at 1M+ Gaussians) alive until Python's cyclic GC happens to run."""
+        self.cb = None
+
 
 def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
@@ -230,6 +260,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         with torch.cuda.device(dev):
             rc = L.radegs_forward(ctypes.byref(a), geom.cb, None, binning.cb, None, img.cb, None, _stream(dev))
         for r in (geom, binning, img):
+            r.release()
             if r.error is not None:
                 raise r.error
         rendered = _check(rc, "radegs_forward")
@@ -249,9 +280,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
     fo = dict(dtype=torch.float32, device=dev)
 
+    grad_alloc = _grad_allocator_for(dev)
+
     def mk(name, shape):
-        if P != 0 and GRAD_ALLOCATOR is not None:
-            t = GRAD_ALLOCATOR(name, shape, torch.float32, dev)
+        if P != 0 and grad_alloc is not None:
+            t = grad_alloc(name, shape, torch.float32, dev)
             if t is not None:
                 assert t.shape == torch.Size(shape) and t.is_contiguous() and t.dtype == torch.float32 and t.device == dev
                 return t
@@ -261,9 +294,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dopacity, dL_dcov3D = mk("dL_dopacity", (P, 1)), mk("dL_dcov3D", (P, 6))
     drgb = None
     skip_dsh = False
-    if P != 0 and M != 0 and GRAD_ALLOCATOR is not None:
-        drgb = GRAD_ALLOCATOR("dL_drgb_clamped", (P, 3), torch.float32, dev)
-        skip_dsh = drgb is not None and GRAD_ALLOCATOR("dL_dsh", (P, M, 3), torch.float32, dev) is SKIP_GRAD
+    if P != 0 and M != 0 and grad_alloc is not None:
+        drgb = grad_alloc("dL_drgb_clamped", (P, 3), torch.float32, dev)
+        skip_dsh = drgb is not None and grad_alloc("dL_dsh", (P, M, 3), torch.float32, dev) is SKIP_GRAD
         if drgb is not None:
             assert drgb.shape == torch.Size((P, 3)) and drgb.is_contiguous() and drgb.dtype == torch.float32 and drgb.device == dev
     dL_dsh = None if skip_dsh else mk("dL_dsh", (P, M, 3))
@@ -290,6 +323,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                           int(bool(require_coord)), int(bool(require_depth)), int(bool(debug)), _ptr(drgb))
         with torch.cuda.device(dev):
             rc = L.radegs_backward(ctypes.byref(a), acc.cb, None, _stream(dev))
+        acc.release()
         if acc.error is not None:
             raise acc.error
         _check(rc, "radegs_backward")
@@ -369,6 +403,7 @@ def integrate_gaussians_to_points(background, points3D, means3D, colors, opacity
     with torch.cuda.device(dev):
         rc = L.radegs_integrate(ctypes.byref(a), geom.cb, None, binning.cb, None, img.cb, None, pts.cb, None, _stream(dev))
     for r in (geom, binning, img, pts):
+        r.release()
         if r.error is not None:
             raise r.error
     rendered = _check(rc, "radegs_integrate")

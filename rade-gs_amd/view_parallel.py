@@ -60,7 +60,7 @@ def allreduce_densification_stats(grad_norm_xy: torch.Tensor, grad_norm_abs: tor
 
 class GradBucket:
     """One flat fp32 buffer holding the parameter gradients of a view back to back (59 floats = 236 B per
-    Gaussian at SH degree 3).  Install `bucket.allocator` as `_C.GRAD_ALLOCATOR` and the backward kernels write
+    Gaussian at SH degree 3).  Install `bucket.allocator` with `_C.set_grad_allocator(device, ...)` and the backward kernels write
     straight into it; `allreduce()` is then a single RCCL call on the bucket, no packing copy."""
 
     LAYOUT = ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations")
@@ -97,7 +97,7 @@ class FactoredGradExchange:
         here    all-reduce  44 B + all-gather (N-1) * 12 B        = 161 B per Gaussian at N = 8
     The result equals the plain all-reduce up to fp32 summation order.  GPU only (the rebuild is a HIP kernel).
 
-    Usage: `_C.GRAD_ALLOCATOR = ex.allocator` before the backward; `ex.exchange(means3D, campos)` after it."""
+    Usage: `_C.set_grad_allocator(device, ex.allocator)` before the backward; `ex.exchange(means3D, campos)` after it."""
 
     SMALL = ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations")
 

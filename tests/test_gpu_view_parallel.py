@@ -36,11 +36,11 @@ def test_factored_sh_gradient_equals_sum_over_views(deg):
     try:
         for v in views:
             s = to_device(v, dev)
-            C.GRAD_ALLOCATOR = None
+            C.set_grad_allocator(dev, None)
             bw = _backward(C, s, g, e)
             plain = bw[5].clone() if plain is None else plain + bw[5]
             ex = FactoredGradExchange(P, M, deg, dev)
-            C.GRAD_ALLOCATOR = ex.allocator
+            C.set_grad_allocator(dev, ex.allocator)
             bw2 = _backward(C, s, g, e)
             assert bw2[5] is None                                  # the (P,M,3) tensor is neither allocated nor written
             for a, b in ((bw[3], bw2[3]), (bw[2], bw2[2]), (bw[6], bw2[6]), (bw[7], bw2[7]), (bw[1], bw2[1])):
@@ -54,7 +54,7 @@ def test_factored_sh_gradient_equals_sum_over_views(deg):
             drgb.append(ex.drgb.clone())
             campos.append(s.campos.clone())
     finally:
-        C.GRAD_ALLOCATOR = None
+        C.set_grad_allocator(dev, None)
     total = C.sh_grad_from_views(to_device(base, dev).means3D, torch.stack(campos), torch.stack(drgb), deg, M, 1.0 / 3.0)
     ref = plain / 3.0
     assert (total - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-12
