@@ -159,7 +159,11 @@ def test_precomputed_colors_and_covariance():
     check_backward(s, o, colors=colors, cov3D=cov, seed=5)
 
 
-def test_flat_gaussians_ill_conditioned_branch():
+@pytest.mark.parametrize("streams", [0, 1])
+def test_flat_gaussians_ill_conditioned_branch(streams, monkeypatch):
+    """Flat (needle-like on screen) Gaussians: the eigen-solver's ill-conditioned branch, conics whose quadratic form is a
+    difference of huge terms -- both blend paths must evaluate it in the reference's order of operations."""
+    monkeypatch.setenv("RADEGS_STREAMS", str(streams))
     from test_hostcheck import _flat_scene
     s = _flat_scene(make_scene(2500, 160, 120, sh_degree=1, mu_px=3.0, seed=12, kernel_size=0.0, pose="random", require_coord=True,
                                require_depth=True))
