@@ -8,9 +8,13 @@
 A "step" is one pass of the hot path over one synthetic view: `_C.rasterize_gaussians` followed by
 `_C.rasterize_gaussians_backward` with fixed random cotangents (allocation of outputs/grads included,
 loss arithmetic excluded -- SURVEY.md 8d).  Workload at N=1: BASELINE.json configs[1] ("C2": 1M
-Gaussians, 1920x1080, SH degree 3, RGB + depth + normal).  For N>1 every rank renders its OWN view of
-the replicated Gaussians (weak scaling) and the step ends with one RCCL all-reduce of the 236 B/Gaussian
-parameter gradients.  Inputs are resident in HBM before the timed region.
+Gaussians, 1920x1080, SH degree 3, RGB + depth + normal); `--config C3|C4|C5` measures the other
+BASELINE configs the same way.  Like training (train.py:118 picks another camera every iteration) the
+steps walk a STREAM OF DIFFERENT VIEWS of the same Gaussians: the config's own view, `--views`-2
+neighbouring ones (2 deg / 0.05 units apart) and one dolly-in view whose num_rendered is well above the
+others' (what the speculative binning's capacity prediction has to survive; `speculation.miss_rate` says how
+often it did not).  For N>1 every rank walks its OWN views of the replicated Gaussians (weak scaling) and the
+step ends with the RCCL exchange of the parameter gradients.  Inputs are resident in HBM before the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      dominant kernel: algorithmic bytes per launch / its average
@@ -61,6 +65,7 @@ def main():
     ap.add_argument("--config", default="C2", help="BASELINE.json config (C1..C5); the headline metric is quoted on C2")
     ap.add_argument("--points", type=int, default=0, help="override the number of Gaussians (debug only)")
     ap.add_argument("--mu-px", type=float, default=0.0, help="override the median splat size in pixels (debug only)")
+    ap.add_argument("--views", type=int, default=9, help="distinct camera views the steps rotate through (1 = the same view every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-allreduce", action="store_true", help="run the RCCL gradient exchange even at world size 1 (path check)")
     ap.add_argument("--exchange", choices=("factored", "allreduce"), default="factored",
@@ -94,9 +99,17 @@ def main():
         over["mu_px"] = args.mu_px
     cfg = dict(CONFIGS[args.config])
     scene_cpu = make_config(args.config, **over)
-    if world > 1:  # the SAME Gaussians on every rank, each rank renders its own neighbouring view of them (rank 0: the config's view)
-        scene_cpu = jittered_view(scene_cpu, rank) if rank else scene_cpu
+    # the view stream of this rank: view 0 of rank 0 is the config's own view; the last one is the dolly-in view
+    nviews = max(1, args.views)
+    views_cpu = []
+    for k in range(nviews):
+        vid = rank * 64 + k
+        if vid == 0:
+            views_cpu.append(scene_cpu)
+        else:
+            views_cpu.append(jittered_view(scene_cpu, vid, dolly=0.6 if (nviews > 2 and k == nviews - 1) else 0.0))
     s = to_device(scene_cpu, dev)
+    cams = [tuple(t.to(dev) for t in (v.viewmatrix, v.projmatrix, v.campos)) for v in views_cpu]
     g = {k: v.to(dev) for k, v in upstream_grads(scene_cpu, cfg["seed"]).items()}
     P, W, H = s.means3D.shape[0], s.W, s.H
     e = torch.Tensor([])
@@ -107,19 +120,22 @@ def main():
         else:
             bucket = GradBucket(P, s.shs.shape[1], dev)
         C.set_grad_allocator(dev, bucket.allocator)
+    counter = [0]
 
     def step():
-        fw = C.rasterize_gaussians(s.bg, s.means3D, e, s.opacities, s.scales, s.rotations, 1.0, e, s.viewmatrix, s.projmatrix, s.tanfovx,
-                                   s.tanfovy, s.kernel_size, H, W, s.shs, s.sh_degree, s.campos, False, s.require_coord,
+        vm, pm, cp = cams[counter[0] % nviews]
+        counter[0] += 1
+        fw = C.rasterize_gaussians(s.bg, s.means3D, e, s.opacities, s.scales, s.rotations, 1.0, e, vm, pm, s.tanfovx,
+                                   s.tanfovy, s.kernel_size, H, W, s.shs, s.sh_degree, cp, False, s.require_coord,
                                    s.require_depth, False)
         R, color, coord, mcoord, alpha, normal, depth, mdepth, radii, geom, binning, img = fw
-        bw = C.rasterize_gaussians_backward(s.bg, s.means3D, radii, e, s.scales, s.rotations, 1.0, e, s.viewmatrix, s.projmatrix,
+        bw = C.rasterize_gaussians_backward(s.bg, s.means3D, radii, e, s.scales, s.rotations, 1.0, e, vm, pm,
                                             s.tanfovx, s.tanfovy, s.kernel_size, g["color"], g["coord"], g["mcoord"], g["depth"],
-                                            g["mdepth"], g["alpha"], g["normal"], normal, s.shs, s.sh_degree, s.campos, geom, R,
+                                            g["mdepth"], g["alpha"], g["normal"], normal, s.shs, s.sh_degree, cp, geom, R,
                                             binning, img, alpha, s.require_coord, s.require_depth, False)
         grads = dict(dL_dmeans3D=bw[3], dL_dsh=bw[5], dL_dopacity=bw[2], dL_dscales=bw[6], dL_drotations=bw[7])
         if bucket is not None:  # the one exchange step of the path (RCCL over xGMI)
-            grads = bucket.exchange(s.means3D, s.campos, average=True) if args.exchange == "factored" else bucket.allreduce(average=True)
+            grads = bucket.exchange(s.means3D, cp, average=True) if args.exchange == "factored" else bucket.allreduce(average=True)
         return R, radii, grads
 
     def fence():
@@ -144,12 +160,17 @@ def main():
     if args.warmup > 0:
         dom = max(("preprocess_fwd", "blend_fwd", "blend_bwd", "preprocess_bwd"), key=lambda k: stages_warm[k][0] / max(stages_warm[k][1], 1))
     C.profile_enable(True, only=dom)   # no warm-up steps: fall back to recording every stage inside the timed region
+    C.binning_stats(reset=True)
+    Rs, vis = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         R, radii, _ = step()
+        Rs.append(R)
+        vis.append(radii)          # kept alive, counted after the timed region
     fence()
     elapsed = time.perf_counter() - t0
     C.profile_enable(False)
+    spec_calls, spec_misses = C.binning_stats()
     timed = C.profile_collect()
     if dom is None:
         stages = timed
@@ -165,7 +186,9 @@ def main():
     value = world * P / 1e6 / (elapsed / args.steps)
 
     if rank == 0:
-        Pv = int((radii > 0).sum().item())
+        # algorithmic bytes: per-step averages over the views the timed steps rendered
+        Pv = int(round(sum(int((r > 0).sum().item()) for r in vis) / max(len(vis), 1)))
+        R = int(round(sum(Rs) / max(len(Rs), 1)))
         c, d = int(s.require_coord), int(s.require_depth)
         ab = algorithmic_bytes(P, Pv, R, W * H, s.sh_degree, c, d)
         ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in stages.items()}
@@ -178,15 +201,17 @@ def main():
         kernel_name = {"blend_bwd": "blend_bwd_"}.get(dom, dom + "_")   # prefix of the kernel's name in the rocprof summaries
         traffic, traffic_note = pmc_traffic(kernel_name, args.config, P, W, H)
         out = {
-            "metric": "fwd+bwd Msplats/s @1080p, 1M Gaussians; depth L1 vs ref", "value": round(value, 2), "unit": "Msplats/s",
+            "metric": "fwd+bwd Msplats/s @1080p, 1M Gaussians; depth L1 vs ref" if args.config == "C2" else f"fwd+bwd Msplats/s, {args.config}", "value": round(value, 2), "unit": "Msplats/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH degree {s.sh_degree}, fwd+bwd single view per GPU, "
+            "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH degree {s.sh_degree}, fwd+bwd one view per step per GPU, "
                                    f"RGB{'+coord' if c else ''}{'+depth' if d else ''}{'+normal' if (c or d) else ''}",
                        "parallelism": f"view-parallel x{world}" + ((", RCCL all-reduce of 44 B + all-gather of 12 B/Gaussian/view (SH gradient factored)"
                                                                      if args.exchange == "factored" else ", RCCL all-reduce of 236 B/Gaussian grads")
                                                                     if world > 1 else ""),
-                       "num_rendered": int(R), "visible": Pv},
+                       "views": nviews, "num_rendered": int(R), "num_rendered_min_max": [int(min(Rs)), int(max(Rs))], "visible": Pv},
+            "speculation": {"speculative_forwards": spec_calls, "redone": spec_misses,
+                            "miss_rate": round(spec_misses / spec_calls, 4) if spec_calls else None},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": int(ab[dom]), "avg_launch_ms": round(dom_ms, 4)},
@@ -212,11 +237,14 @@ def pmc_traffic(kernel_name, config, P, W, H):
     prescribes; its gfx950 note applies: 16-B/lane streaming reads may be under-counted up to 2x).  Counters cannot be
     collected inside a timed run, so the value is only reported for the workload the pass was made on; else null."""
     import glob
-    if (config, P, W, H) != ("C2", 1_000_000, 1920, 1080):
+    from synth_scene import CONFIGS
+    c = CONFIGS.get(config)
+    if c is None or (P, W, H) != (c["P"], c["W"], c["H"]):
         return None, "no PMC pass for this workload"
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_per_kernel.json")))
+    tag = "" if config == "C2" else "_" + config
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r[0-9][0-9]{tag}_pmc_per_kernel.json")))
     if not files:
-        return None, "profiles/*_pmc_per_kernel.json not found"
+        return None, f"profiles/rNN{tag}_pmc_per_kernel.json not found"
     try:
         d = json.load(open(files[-1]))
         for name, v in d.items():

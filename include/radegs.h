@@ -196,6 +196,10 @@ size_t radegs_binning_bytes(int R);
 long long radegs_debug_export(const char* name, int P, int R, int width, int height, int require_coord, const void* geom_buffer,
                               const void* binning_buffer, const void* image_buffer, void* dst, size_t dst_bytes, void* stream);
 
+/* Speculative binning (see radegs_forward): forwards that ran on a predicted capacity / those whose prediction was too small and
+ * were redone with exact sizes, since the last reset. */
+void radegs_binning_stats(unsigned long long* speculative_calls, unsigned long long* misses, int reset);
+
 /* Per-stage timing with HIP events recorded on the launch stream (used by bench.py for the live
  * roofline measurement).  enable(1) -> every subsequent forward/backward records an event pair per
  * stage; collect() waits for them, adds each stage's elapsed ms / launch count into the arrays

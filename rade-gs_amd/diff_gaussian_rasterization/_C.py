@@ -76,7 +76,7 @@ class RadegsIntegrateArgs(ctypes.Structure):
 # every symbol include/radegs.h declares
 EXPORTED_SYMBOLS = ("radegs_forward", "radegs_backward", "radegs_mark_visible", "radegs_integrate", "radegs_sh_grad_from_views", "radegs_geometry_bytes", "radegs_image_bytes",
                     "radegs_binning_bytes", "radegs_debug_export", "radegs_last_error", "radegs_version", "radegs_profile_enable",
-                    "radegs_profile_select", "radegs_profile_num_stages", "radegs_profile_stage_name", "radegs_profile_collect",
+                    "radegs_profile_select", "radegs_binning_stats", "radegs_profile_num_stages", "radegs_profile_stage_name", "radegs_profile_collect",
                     # fused pre/post steps (bound in graphics_utils.py / gaussian_model_ops.py)
                     "radegs_normals_forward", "radegs_normals_backward", "radegs_normal_loss_scratch_bytes",
                     "radegs_normal_loss_forward", "radegs_normal_loss_backward", "radegs_normals_last_error",
@@ -154,6 +154,8 @@ def library():
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.radegs_last_error.restype = ctypes.c_char_p
         L.radegs_version.restype = ctypes.c_char_p
+        L.radegs_binning_stats.restype = None
+        L.radegs_binning_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
         L.radegs_profile_enable.restype = None
         L.radegs_profile_enable.argtypes = [ctypes.c_int]
         L.radegs_profile_select.restype = None
@@ -427,6 +429,13 @@ def debug_export(name, dtype, numel, P, R, W, H, require_coord, geomBuffer, binn
     if n < 0:
         raise RuntimeError(L.radegs_last_error().decode())
     return dst
+
+
+def binning_stats(reset=False):
+    """(speculative forwards, forwards redone because the predicted capacity was too small) since the last reset."""
+    calls, misses = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
+    library().radegs_binning_stats(ctypes.byref(calls), ctypes.byref(misses), int(bool(reset)))
+    return int(calls.value), int(misses.value)
 
 
 def profile_enable(on=True, only=None):

@@ -157,10 +157,12 @@ def make_config(name, **over) -> Scene:
     return make_scene(**kw)
 
 
-def jittered_view(scene: Scene, seed, angle_deg=2.0, shift=0.05, fovx_deg=60.0) -> Scene:
+def jittered_view(scene: Scene, seed, angle_deg=2.0, shift=0.05, fovx_deg=60.0, dolly=0.0) -> Scene:
     """The same Gaussians seen from a slightly different camera (rotation by `angle_deg` about a random axis, translation by
     `shift`): what neighbouring training views look like.  Used for the per-rank views of the view-parallel bench so that
-    every rank has the workload of the named config (an unrelated random pose would see almost none of the Gaussians)."""
+    every rank has the workload of the named config (an unrelated random pose would see almost none of the Gaussians).
+    dolly > 0 additionally moves the camera that far INTO the scene: splats grow, num_rendered jumps -- the view a capacity
+    prediction made on the others is too small for."""
     gen = _Rng(777_000 + int(seed))
     w2c = scene.viewmatrix.double().numpy().T
     axis = gen.randn(3)
@@ -171,6 +173,7 @@ def jittered_view(scene: Scene, seed, angle_deg=2.0, shift=0.05, fovx_deg=60.0) 
     d = np.eye(4)
     d[:3, :3] = dR
     d[:3, 3] = gen.randn(3) * shift
+    d[2, 3] -= dolly
     w2c = d @ w2c
     fovx, fovy = 2 * math.atan(scene.tanfovx), 2 * math.atan(scene.tanfovy)
     viewmatrix = w2c.T.copy()

@@ -58,6 +58,19 @@ def allreduce_densification_stats(grad_norm_xy: torch.Tensor, grad_norm_abs: tor
     return a.to(grad_norm_xy.dtype), b.to(grad_norm_abs.dtype), c.to(visible.dtype), r
 
 
+def assert_same_on_all_ranks(what: str, values, group=None):
+    """Fails LOUDLY on every rank when the ranks disagree on the sizes the collectives below are built from -- a mismatch would
+    otherwise show up as a hang inside RCCL (all_gather_into_tensor / all_reduce block forever on unequal counts)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    mine = [int(v) for v in values]
+    everyone = [None] * dist.get_world_size(group)
+    dist.all_gather_object(everyone, mine, group=group)
+    if any(v != mine for v in everyone):
+        raise RuntimeError(f"view-parallel exchange: ranks disagree on {what}: {everyone} (this rank: {mine}); "
+                           "every rank must hold the same replicated Gaussians")
+
+
 class GradBucket:
     """One flat fp32 buffer holding the parameter gradients of a view back to back (59 floats = 236 B per
     Gaussian at SH degree 3).  Install `bucket.allocator` with `_C.set_grad_allocator(device, ...)` and the backward kernels write
@@ -65,7 +78,8 @@ class GradBucket:
 
     LAYOUT = ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations")
 
-    def __init__(self, P: int, M: int, device):
+    def __init__(self, P: int, M: int, device, group=None):
+        assert_same_on_all_ranks("(P, M)", (P, M), group)
         shapes = {"dL_dmeans3D": (P, 3), "dL_dsh": (P, M, 3), "dL_dopacity": (P, 1), "dL_dscales": (P, 3), "dL_drotations": (P, 4)}
         sizes = [int(torch.Size(shapes[k]).numel()) for k in self.LAYOUT]
         self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
@@ -104,6 +118,7 @@ class FactoredGradExchange:
     def __init__(self, P: int, M: int, degree: int, device, group=None):
         from diff_gaussian_rasterization import _C
         self._C, self.P, self.M, self.D, self.group = _C, P, M, degree, group
+        assert_same_on_all_ranks("(P, M, sh_degree)", (P, M, degree), group)
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         shapes = {"dL_dmeans3D": (P, 3), "dL_dopacity": (P, 1), "dL_dscales": (P, 3), "dL_drotations": (P, 4)}
         sizes = [int(torch.Size(shapes[k]).numel()) for k in self.SMALL]

@@ -169,3 +169,32 @@ def test_factored_exchange_two_ranks(tmp_path):
         flat = torch.cat([o[k].reshape(-1) for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations")])
         torch.testing.assert_close(flat, small)
     assert torch.equal(outs[0]["out"]["dL_dsh"], outs[1]["out"]["dL_dsh"])
+
+
+def _mismatch_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "rade-gs_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from view_parallel import FactoredGradExchange, GradBucket
+    msgs = []
+    for make in (lambda: FactoredGradExchange(100 + rank, 16, 3, torch.device("cpu")), lambda: GradBucket(100 + rank, 16, "cpu")):
+        try:
+            make()
+            msgs.append("no error")
+        except RuntimeError as ex:
+            msgs.append(str(ex))
+    with open(os.path.join(out_dir, f"m{rank}.txt"), "w") as f:
+        f.write("\n".join(msgs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_size_mismatch_fails_loudly_instead_of_hanging(tmp_path):
+    """Ranks that disagree on the number of Gaussians would block forever inside the collectives; both exchange objects check
+    the sizes once, at construction, and every rank raises."""
+    world = 2
+    mp.spawn(_mismatch_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        lines = open(os.path.join(tmp_path, f"m{r}.txt")).read().splitlines()
+        assert len(lines) == 2 and all("ranks disagree" in l for l in lines), lines
