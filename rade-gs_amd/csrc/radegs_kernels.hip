@@ -477,7 +477,7 @@ struct BlendFwdArgs {
   const float* bg;
   float* out_color; float* out_coord; float* out_mcoord; float* out_depth; float* out_mdepth; float* out_alpha; float* out_normal;
   uint32_t* n_contrib; float* accum_coord; float* accum_depth; float* normal_length;
-  const uint32_t* blk_count; uint32_t* blk_consumed; uint32_t* blk_chunks;   // sub-tile entry streams (rg_streams.inc)
+  const uint32_t* blk_count; uint32_t* blk_consumed; uint32_t* blk_chunks; const uint32_t* blk_order;   // sub-tile entry streams (rg_streams.inc)
 };
 
 // blockIdx -> work item such that each XCD (block b runs on XCD b % 8) owns a contiguous band.
@@ -752,7 +752,7 @@ struct BlendBwdArgs {
   const float* dL_dpix; const float* dL_dcoord; const float* dL_dmcoord; const float* dL_ddepth; const float* dL_dmdepth;
   const float* dL_dalpha; const float* dL_dnormal;
   float* acc;  // [P][REC] per-Gaussian sums, SplatAcc order
-  const uint32_t* blk_consumed; const uint32_t* blk_chunks;   // sub-tile entry streams (rg_streams.inc)
+  const uint32_t* blk_consumed; const uint32_t* blk_chunks; const uint32_t* blk_order;   // sub-tile entry streams (rg_streams.inc)
 };
 
 // In: v[i] = this lane's partial sum of component i.  Out (return value): the wave-wide total of

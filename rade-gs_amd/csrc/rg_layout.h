@@ -119,6 +119,7 @@ struct ImageState {
   // bases below depend on (W, H) alone: the backward finds them without knowing the capacity the forward allocated for.
   uint32_t* blk_count;     // [8*tiles] entries in each block's list
   uint32_t* blk_consumed;  // [8*tiles] entries of it the forward walked before all of the block's pixels had terminated
+  uint32_t* blk_order;     // [8*tiles] block ids (tile*8 + block) in wave order: wave w of the blend kernels walks entries 4w..4w+3
   uint32_t* blk_chunks;    // [stream_chunk_capacity(stream_R, tiles) * kChunkWords]
   size_t total;
   static ImageState carve(void* buf, size_t W, size_t H, size_t stream_R = 0) {
@@ -132,6 +133,7 @@ struct ImageState {
     s.normal_length = c.take<float>(N);
     s.blk_count = c.take<uint32_t>(kBlocksPerTile * tiles);
     s.blk_consumed = c.take<uint32_t>(kBlocksPerTile * tiles);
+    s.blk_order = c.take<uint32_t>(kBlocksPerTile * tiles);
     s.blk_chunks = c.take<uint32_t>(stream_R ? stream_chunk_capacity(stream_R, tiles) * kChunkWords : 0);
     s.total = c.total();
     return s;
