@@ -1376,6 +1376,22 @@ struct PreBwdArgs {
 // moves its contiguous 128-row slab with coalesced accesses through LDS (row stride 3M+1 words: odd, so the
 // per-thread row walks are bank-conflict free); sh and dL/dsh share the slab (sh_bwd's access order allows it).
 constexpr int kPreBwdThreads = 128;
+// Copies a block's contiguous [nrows][rowf] slab between global memory and the LDS slab of row stride rowf + 1, 128 consecutive
+// words per step.  (row, column) of word e come from a multiply-high by the reciprocal of the run-time row length (exact for
+// the slab's few thousand words): a true division per word cost more than everything else the kernel does, and carrying
+// (row, column) from step to step serialises the loads.
+template <bool TO_LDS>
+__device__ __forceinline__ void slab_copy(float* slab, float* gmem, int nrows, int rowf, int tid) {
+  const int stride = rowf + 1, n = nrows * rowf;
+  const uint32_t magic = 0xFFFFFFFFu / (uint32_t)rowf + 1u;   // ceil(2^32 / rowf): floor(e / rowf) == mulhi(e, magic) for e * rowf < 2^32
+#pragma unroll 4
+  for (int e = tid; e < n; e += kPreBwdThreads) {
+    const int g = (int)__umulhi((uint32_t)e, magic), c = e - g * rowf;
+    if constexpr (TO_LDS) slab[g * stride + c] = gmem[e];
+    else gmem[e] = slab[g * stride + c];
+  }
+}
+
 __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const PreBwdArgs a) {
   extern __shared__ float sh_slab[];  // [128][3M+1]
   const int tid = threadIdx.x;
@@ -1385,11 +1401,7 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
   const int rowf = a.M * 3, stride = rowf + 1;
   const bool have_sh = a.shs != nullptr;
   if (have_sh) {
-    const float* src = a.shs + (size_t)base * rowf;
-    for (int e = tid; e < nrows * rowf; e += kPreBwdThreads) {
-      const int g = e / rowf, c = e - g * rowf;
-      sh_slab[g * stride + c] = src[e];
-    }
+    slab_copy<true>(sh_slab, const_cast<float*>(a.shs) + (size_t)base * rowf, nrows, rowf, tid);
     __syncthreads();
   }
   if (idx < a.P) {
@@ -1479,11 +1491,7 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
   }
   if (have_sh && a.dL_dsh) {
     __syncthreads();
-    float* dst = a.dL_dsh + (size_t)base * rowf;
-    for (int e = tid; e < nrows * rowf; e += kPreBwdThreads) {
-      const int g = e / rowf, c = e - g * rowf;
-      dst[e] = sh_slab[g * stride + c];
-    }
+    slab_copy<false>(sh_slab, a.dL_dsh + (size_t)base * rowf, nrows, rowf, tid);
   }
 }
 
@@ -1520,11 +1528,7 @@ __global__ void __launch_bounds__(kPreBwdThreads) sh_grad_from_views_kernel(int 
     for (int c = 48; c < rowf; c++) row[c] = 0.f;
   }
   __syncthreads();
-  float* dst = dL_dsh + (size_t)base * rowf;
-  for (int e = tid; e < nrows * rowf; e += kPreBwdThreads) {
-    const int g = e / rowf, c = e - g * rowf;
-    dst[e] = sh_slab[g * stride + c];
-  }
+  slab_copy<false>(sh_slab, dL_dsh + (size_t)base * rowf, nrows, rowf, tid);
 }
 
 }  // namespace rg
