@@ -9,7 +9,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"      # "r02" (C2) or "r02_C4" etc.
 src = os.path.join(ROOT, "gpurun_out", "profiles_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -27,10 +27,14 @@ for name in ("pmc_sq", "pmc_tcc"):
     if not os.path.exists(p):
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(p)):
-        k = r["Kernel_Name"]
-        if "rg::" in k:
-            agg[k.split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    rows_c = list(csv.DictReader(open(p)))
+    # the counters of the LAST dispatches only: the first ones of a process run on cold caches / exact-size buffers
+    per_kernel = collections.defaultdict(list)
+    for r in rows_c:
+        if "rg::" in r["Kernel_Name"]:
+            per_kernel[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (k, c), vals in per_kernel.items():
+        agg[k][c] = vals[len(vals) // 2:]
     for k, v in agg.items():
         out.setdefault(k, {}).update({c: round(sum(x) / len(x)) for c, x in v.items()})
 for k, v in out.items():
