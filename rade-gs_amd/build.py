@@ -7,6 +7,10 @@ hipcc cross-compiles without a GPU.  Flags that matter:
                            what makes radii / tile rects / depth keys / blend decisions bit-identical to
                            the CPU oracle (see csrc/rg_math.h, csrc/rg_blend.h).
   -munsafe-fp-atomics      global_atomic_add_f32 in hardware (no CAS loop) for the gradient accumulators.
+  -fno-slp-vectorize       keeps clang from fusing the two pixels' (or any two independent) fp32 chains into v_pk_* instructions:
+                           packed fp32 issues as two passes on gfx950 (no throughput gain, scripts/ubench/valu_rates.hip) and the
+                           fused chains lose the instruction-level parallelism of two independent ones -- measured on C2: forward
+                           blend 0.36 -> 0.32 ms, backward 0.60 -> 0.57, preprocess_bwd 0.21 -> 0.18.
   (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt stays on: IEEE divide/sqrt.)
 """
 import os
@@ -21,7 +25,7 @@ LIB = os.path.join(OUT_DIR, "libradegs_hip.so")
 CHECK_LIB = os.path.join(OUT_DIR, "libradegs_prims_check.so")   # test-only: rocPRIM cross-check of the hand-written sorts
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
-         "-Wno-unused-value", "-I", CSRC]
+         "-fno-slp-vectorize", "-Wno-unused-value", "-I", CSRC]
 UNITS = {
     "radegs_prims": ["radegs_prims.hip"],
     "radegs_sort": ["radegs_sort.hip", "rg_prims.h"],

@@ -38,6 +38,27 @@ RG_HD float exp_spec(float x) {
   return u.f;
 }
 
+// The same value as exp_spec(x) for x >= -87; below, exp_spec(-87) (~1.6e-38) instead of 0.  For callers that only use the result
+// through `op * exp < 1/255` (any op <= 1 fails it either way): straight-line code, no branch between two pixels' evaluations.
+RG_HD float exp_spec_floor(float x) {
+  x = fmaxf(x, -87.0f);
+  const float kf = rintf(x * 1.44269504088896341f);
+  float r = fmaf(kf, -0.693359375f, x);
+  r = fmaf(kf, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = fmaf(p, r, 1.3981999507e-3f);
+  p = fmaf(p, r, 8.3334519073e-3f);
+  p = fmaf(p, r, 4.1665795894e-2f);
+  p = fmaf(p, r, 1.6666665459e-1f);
+  p = fmaf(p, r, 5.0000001201e-1f);
+  const float r2 = r * r;
+  const float y = fmaf(p, r2, r) + 1.0f;
+  union { float f; int32_t i; } u;
+  u.f = y;
+  u.i += ((int32_t)kf) << 23;
+  return u.f;
+}
+
 // Conservative skip threshold: any power below it gives alpha < 1/255 under the exact rule
 // (margin 1e-3 in the exponent >> the 1e-6 relative error of exp_spec and of logf).  op <= 0
 // gives +inf (always skip: alpha <= 0 < 1/255); NaN makes the prefilter a no-op and the exact

@@ -19,7 +19,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libradegs_hip.so")
+_LIB_PATH = os.environ.get("RADEGS_LIB") or os.path.join(_HERE, "libradegs_hip.so")   # RADEGS_LIB: A/B runs of two builds
 
 _ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
 _F = ctypes.POINTER(ctypes.c_float)
