@@ -51,6 +51,8 @@ def lib():
         L.oracle_mark_visible.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4
         L.oracle_exp_spec.restype = ctypes.c_float
         L.oracle_exp_spec.argtypes = [ctypes.c_float]
+        L.oracle_set_exp_mode.restype = None
+        L.oracle_set_exp_mode.argtypes = [ctypes.c_int]
         L.oracle_higher_msb.restype = ctypes.c_uint
         L.oracle_higher_msb.argtypes = [ctypes.c_uint]
         L.oracle_kat_mat3.restype = None
@@ -176,6 +178,12 @@ def mark_visible(means3D, viewmatrix, projmatrix):
 
 def exp_spec(x):
     return float(lib().oracle_exp_spec(ctypes.c_float(x)))
+
+
+def set_exp_mode(mode):
+    """0 = specified exp (default); 1 = libm expf; 2 / 3 = the specification one ulp up / down.  Sensitivity experiments only:
+    always restore 0."""
+    lib().oracle_set_exp_mode(int(mode))
 
 
 def higher_msb(n):

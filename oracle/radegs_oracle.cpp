@@ -47,7 +47,18 @@ static constexpr int TILE = 16;  // BLOCK_X = BLOCK_Y, DGR/cuda_rasterizer/confi
 // fma); degree-5 polynomial (Cephes expf coefficients) evaluated with fma; scale by 2^k
 // through the exponent field.  x < -87 returns 0 (keeps 2^k normal).  The HIP kernels
 // restate this sequence operation for operation (csrc/rg_blend.h).
+// g_exp_mode (oracle_set_exp_mode; tests/test_oracle_exp_sensitivity.py only): 0 = the specification; 1 = the C library's
+// expf; 2 / 3 = the specification moved one ulp up / down.  The non-zero modes stand in for "a build whose expf rounds
+// differently" (CUDA's expf is not reproducible off-device) to measure how many thresholded decisions that can flip.
+static int g_exp_mode = 0;
+inline float exp_spec_impl(float x);
 inline float exp_spec(float x) {
+  if (g_exp_mode == 0) return exp_spec_impl(x);
+  if (g_exp_mode == 1) return std::exp(x);
+  const float y = exp_spec_impl(x);
+  return y > 0.0f ? std::nextafter(y, g_exp_mode == 2 ? 2.0f * y : 0.0f) : y;
+}
+inline float exp_spec_impl(float x) {
   if (x < -87.0f) return 0.0f;
   const float kf = std::rint(x * 1.44269504088896341f);
   float r = __builtin_fmaf(kf, -0.693359375f, x);
@@ -1357,7 +1368,8 @@ void oracle_mark_visible(int P, const float* means3D, const float* view, const f
   }
 }
 
-float oracle_exp_spec(float x) { return exp_spec(x); }
+float oracle_exp_spec(float x) { return exp_spec_impl(x); }
+void oracle_set_exp_mode(int mode) { g_exp_mode = mode; }
 unsigned oracle_higher_msb(unsigned n) { return higher_msb(n); }
 // glm column-major KAT hook (forward.cu:126-133): mat3(1..9) * (1,1,1)
 void oracle_kat_mat3(float out[3]) {
