@@ -16,6 +16,7 @@
 // inter-workgroup communication, deterministic output.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "rg_prims.h"
 
@@ -35,10 +36,16 @@ __global__ void __launch_bounds__(kSortThreads) digit_histogram_kernel(const uin
   h[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t base = blockIdx.x * (uint32_t)(kSortThreads * ITEMS);
-#pragma unroll 4
+  uint32_t k[ITEMS];   // every load is issued before the first one is used (a load per LDS atomic would serialise their latencies)
+#pragma unroll
   for (int r = 0; r < ITEMS; r++) {
     const uint32_t i = base + r * kSortThreads + threadIdx.x;
-    if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
+    k[r] = i < n ? keys[i] : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < ITEMS; r++) {
+    const uint32_t i = base + r * kSortThreads + threadIdx.x;
+    if (i < n) atomicAdd(&h[(k[r] >> shift) & mask], 1u);
   }
   __syncthreads();
   hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];  // [digit][block]
@@ -111,11 +118,23 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const uint32_t* _
   __syncthreads();
   const uint32_t block0 = blockIdx.x * (uint32_t)BLOCK_ITEMS;
   const uint32_t run0 = block0 + wave * (uint32_t)WAVE_ITEMS;  // this wave's contiguous run
-  // ---- phase A: histogram of every wave's run ----
-#pragma unroll 4
+  // the wave's whole run goes to registers first: all 2 x ITEMS loads are in flight together, the keys serve both phases
+  uint32_t rk[ITEMS], rv[ITEMS];
+#pragma unroll
   for (int r = 0; r < ITEMS; r++) {
     const uint32_t i = run0 + r * 64 + lane;
-    if (i < n) atomicAdd(&wave_cnt[wave][(keys_in[i] >> shift) & mask], 1u);
+    rk[r] = i < n ? keys_in[i] : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (int r = 0; r < ITEMS; r++) {
+    const uint32_t i = run0 + r * 64 + lane;
+    rv[r] = i < n ? (vals_in ? vals_in[i] : i) : 0u;
+  }
+  // ---- phase A: histogram of every wave's run ----
+#pragma unroll
+  for (int r = 0; r < ITEMS; r++) {
+    const uint32_t i = run0 + r * 64 + lane;
+    if (i < n) atomicAdd(&wave_cnt[wave][(rk[r] >> shift) & mask], 1u);
   }
   __syncthreads();
   // per digit: the 4 wave counts become exclusive prefixes (wave w starts after waves < w); block total per digit
@@ -129,11 +148,12 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const uint32_t* _
   local_start[tid] = block256_exclusive(block_count, scan_tmp);
   __syncthreads();
   // ---- phase B: stable ranks, 64 consecutive items per step; items land in LDS in digit order ----
+#pragma unroll
   for (int r = 0; r < ITEMS; r++) {
     const uint32_t i = run0 + r * 64 + lane;
     const bool valid = i < n;
-    const uint32_t key = valid ? keys_in[i] : 0xFFFFFFFFu;
-    const uint32_t val = valid ? (vals_in ? vals_in[i] : i) : 0u;
+    const uint32_t key = rk[r];
+    const uint32_t val = rv[r];
     const uint32_t digit = (key >> shift) & mask;
     // lanes holding the same digit (invalid lanes only match each other and are never counted)
     uint64_t peers = __ballot(valid);
@@ -198,16 +218,23 @@ template <bool PACKED>
 __global__ void __launch_bounds__(kSortThreads) gather_block_sums_kernel(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ idx,
                                                                          uint32_t n, uint32_t* __restrict__ block_sums,
                                                                          uint32_t* __restrict__ gathered) {
-  const uint32_t base = blockIdx.x * (uint32_t)(kSortThreads * kScanItems) + threadIdx.x * kScanItems;
+  // the block's 4096 items, striped over the threads (the sum does not care about the order): coalesced index loads and stores,
+  // and all 16 dependent gathers of a thread in flight together
+  const uint32_t base = blockIdx.x * (uint32_t)(kSortThreads * kScanItems) + threadIdx.x;
+  uint32_t id[kScanItems], v[kScanItems];
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    const uint32_t i = base + k * kSortThreads;
+    id[k] = i < n ? (idx ? idx[i] : i) : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) v[k] = id[k] != 0xFFFFFFFFu ? vals[id[k]] : 0u;  // the only random gather
   uint32_t s = 0;
 #pragma unroll
   for (int k = 0; k < kScanItems; k++) {
-    const uint32_t i = base + k;
-    if (i < n) {
-      const uint32_t v = vals[idx ? idx[i] : i];  // the only random gather; the scan pass re-reads it sequentially
-      gathered[i] = v;
-      s += PACKED ? rect_count(v) : v;
-    }
+    const uint32_t i = base + k * kSortThreads;
+    if (i < n) gathered[i] = v[k];   // the scan pass re-reads it sequentially
+    s += PACKED ? rect_count(v[k]) : v[k];
   }
   uint32_t total;
   block_exclusive_scan(s, &total);
@@ -254,7 +281,12 @@ __global__ void __launch_bounds__(kSortThreads) gather_scan_kernel(const uint32_
 
 }  // namespace
 
-static int sort_items_per_thread(size_t n) { return n > (size_t(3) << 20) ? 16 : 8; }
+static int sort_items_per_thread(size_t n) {
+  static const int forced = [] { const char* e = getenv("RADEGS_SORT_ITEMS"); return e ? atoi(e) : 0; }();   // 8 / 16 / 32: measurements only
+  if (forced == 8 || forced == 16 || forced == 32) return forced;
+  // measured (C2 1 M / 3.9 M, C4 5 M / 19.6 M, C5 50 M items): 8 up to 3 M, 16 above, 32 only for tens of millions
+  return n > (size_t(32) << 20) ? 32 : (n > (size_t(3) << 20) ? 16 : 8);
+}
 
 size_t sort_temp_bytes(size_t n) {
   const size_t nblocks = (n + kSortThreads * 8 - 1) / (kSortThreads * 8);  // upper bound over both block sizes
@@ -291,17 +323,18 @@ hipError_t radix_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* k
     const bool to_out = ((passes - 1 - pass) % 2) == 0;
     uint32_t* dst_k = to_out ? keys_out : tkeys;
     uint32_t* dst_v = to_out ? vals_out : tvals;
-    if (items == 16) {
-      hipLaunchKernelGGL(digit_histogram_kernel<16>, dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, (uint32_t)n, shift, mask, hist, nblocks, n_dev);
-      hipLaunchKernelGGL(scan_rows_kernel, dim3(kBins), dim3(kSortThreads), 0, stream, hist, nblocks, totals);
-      hipLaunchKernelGGL(scatter_kernel<16>, dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, src_v, dst_k, dst_v, (uint32_t)n, shift,
-                         mask, nbits, hist, nblocks, totals, n_dev);
-    } else {
-      hipLaunchKernelGGL(digit_histogram_kernel<8>, dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, (uint32_t)n, shift, mask, hist, nblocks, n_dev);
-      hipLaunchKernelGGL(scan_rows_kernel, dim3(kBins), dim3(kSortThreads), 0, stream, hist, nblocks, totals);
-      hipLaunchKernelGGL(scatter_kernel<8>, dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, src_v, dst_k, dst_v, (uint32_t)n, shift,
-                         mask, nbits, hist, nblocks, totals, n_dev);
-    }
+#define RG_SORT_PASS(I_)                                                                                                                   \
+  do {                                                                                                                                     \
+    hipLaunchKernelGGL(digit_histogram_kernel<I_>, dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, (uint32_t)n, shift, mask, hist,  \
+                       nblocks, n_dev);                                                                                                    \
+    hipLaunchKernelGGL(scan_rows_kernel, dim3(kBins), dim3(kSortThreads), 0, stream, hist, nblocks, totals);                               \
+    hipLaunchKernelGGL(scatter_kernel<I_>, dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, src_v, dst_k, dst_v, (uint32_t)n, shift,  \
+                       mask, nbits, hist, nblocks, totals, n_dev);                                                                         \
+  } while (0)
+    if (items == 32) RG_SORT_PASS(32);
+    else if (items == 16) RG_SORT_PASS(16);
+    else RG_SORT_PASS(8);
+#undef RG_SORT_PASS
     src_k = dst_k;
     src_v = dst_v;
   }
