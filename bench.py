@@ -191,7 +191,11 @@ def main():
         R = int(round(sum(Rs) / max(len(Rs), 1)))
         c, d = int(s.require_coord), int(s.require_depth)
         ab = algorithmic_bytes(P, Pv, R, W * H, s.sh_degree, c, d)
-        ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in stages.items()}
+        # per STEP, not per recorded interval: a stage may be timed in several pieces (block_lists: one kernel before the tile sort,
+        # one after it)
+        nrec = {k: v[1] for k, v in stages.items()}
+        per_step = max(nrec.get("preprocess_bwd", 0) if dom != "preprocess_bwd" else nrec.get("blend_bwd", 0), 1)
+        ms = {k: (v[0] / (v[1] if k == dom else per_step) if v[1] else 0.0) for k, v in stages.items()}
         grouped = {"preprocess_fwd": ms["preprocess_fwd"],
                    "binning": ms["sort_depth"] + ms["scan"] + ms["emit_instances"] + ms["sort_tile"] + ms["tile_ranges"],
                    "blend_fwd": ms["blend_fwd"] + ms.get("block_lists", 0.0), "blend_bwd": ms["blend_bwd"] + ms["acc_zero"], "preprocess_bwd": ms["preprocess_bwd"]}

@@ -122,6 +122,11 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* m
 constexpr int kEmitCoopThreshold = 16;
 // rect != nullptr (tile grid at most 255x255): rect[i] is the packed tile rectangle of the i-th Gaussian IN DEPTH ORDER (the scan's
 // gather wrote it): no random access at all here, instead of recomputing the rectangle from three gathers.
+// MASKS (sub-tile entry streams, rg_streams.inc; P < 2^24): the instance value also carries, in its top byte, which of the tile's
+// eight 8x4 blocks the splat can reach (ellipse_tile_mask, rg_blend.h).  Here the splat's record is in registers once for all its
+// tiles and the x-extent of its ellipse over a block row is shared by the tiles of a tile row; after the sort the same question
+// costs a dependent gather per list entry.  block_lists_kernel strips the byte again.
+template <bool MASKS>
 __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32_t* idx_sorted, const uint32_t* offsets,
                                                             const uint32_t* tiles_touched, const float4* splat_a, const int* radii,
                                                             const uint32_t* rect, int gx, int gy, uint32_t* tile_keys, uint32_t* vals,
@@ -132,6 +137,7 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32
   const int lane = threadIdx.x & 63;
   uint32_t idx = 0, ntiles = 0, off = 0;
   int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
   if (i < P) {
     idx = idx_sorted[i];
     if (rect) {
@@ -139,25 +145,53 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32
       x0 = (int)(r & 255u); y0 = (int)((r >> 8) & 255u); x1 = x0 + (int)((r >> 16) & 255u); y1 = y0 + (int)(r >> 24);
       ntiles = (uint32_t)((x1 - x0) * (y1 - y0));
       if (ntiles) off = (i == 0) ? 0u : offsets[i - 1];
+      if (MASKS && ntiles) { q0 = splat_a[4 * (size_t)idx]; q1 = splat_a[4 * (size_t)idx + 1]; }
     } else {
       ntiles = tiles_touched[idx];
       if (ntiles) {
         off = (i == 0) ? 0u : offsets[i - 1];
-        const float4 a0 = splat_a[4 * (size_t)idx];
-        tile_rect(a0.x, a0.y, radii[idx], gx, gy, x0, y0, x1, y1);
+        q0 = splat_a[4 * (size_t)idx];
+        if (MASKS) q1 = splat_a[4 * (size_t)idx + 1];
+        tile_rect(q0.x, q0.y, radii[idx], gx, gy, x0, y0, x1, y1);
       }
     }
   }
   const bool big = ntiles > (uint32_t)kEmitCoopThreshold;
   if (ntiles && !big) {
-    for (int y = y0; y < y1; y++)
+    EllipseSetup e;
+    e.kind = 1;
+    if constexpr (MASKS) {
+      const float U = fmaxf(fabsf((float)(x0 * 16) - q0.x), fabsf((float)(x1 * 16 - 1) - q0.x));
+      const float V = fmaxf(fabsf((float)(y0 * 16) - q0.y), fabsf((float)(y1 * 16 - 1) - q0.y));
+      e = ellipse_setup(q0.x, q0.y, q0.z, q0.w, q1.x, q1.z, U, V);
+    }
+    for (int y = y0; y < y1; y++) {
+      float xl[4] = {0.f, 0.f, 0.f, 0.f}, xh[4] = {0.f, 0.f, 0.f, 0.f};
+      bool hit[4] = {false, false, false, false};
+      if constexpr (MASKS) {
+        if (e.kind == 2) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) hit[r] = ellipse_slab(e, (float)(y * 16 + 4 * r) - q0.y, xl[r], xh[r]);
+        }
+      }
       for (int x = x0; x < x1; x++) {
         if (off < cap) {
+          uint32_t v = idx;
+          if constexpr (MASKS) {
+            uint32_t mask = e.kind == 1 ? 0xFFu : 0u;
+            if (e.kind == 2) {
+              const float ua = (float)(x * 16) - q0.x;
+#pragma unroll
+              for (int r = 0; r < 4; r++) mask |= ellipse_cols(hit[r], xl[r], xh[r], ua) << (2 * r);
+            }
+            v |= mask << kMaskShift;
+          }
           tile_keys[off] = (uint32_t)(y * gx + x);
-          vals[off] = idx;
+          vals[off] = v;
         }
         off++;
       }
+    }
   }
   uint64_t todo = __ballot(big);
   while (todo) {
@@ -165,11 +199,19 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32
     todo &= todo - 1;
     const uint32_t g_idx = __shfl(idx, src), g_n = __shfl(ntiles, src), g_off = __shfl(off, src);
     const int g_x0 = __shfl(x0, src), g_y0 = __shfl(y0, src), g_w = __shfl(x1, src) - g_x0;
+    float g_mx = 0.f, g_my = 0.f, g_cx = 0.f, g_cy = 0.f, g_cz = 0.f, g_thr = 0.f;
+    if constexpr (MASKS) {
+      g_mx = __shfl(q0.x, src); g_my = __shfl(q0.y, src); g_cx = __shfl(q0.z, src); g_cy = __shfl(q0.w, src);
+      g_cz = __shfl(q1.x, src); g_thr = __shfl(q1.z, src);
+    }
     for (uint32_t t = lane; t < g_n; t += 64) {
       const int ty = (int)(t / (uint32_t)g_w), tx = (int)(t - (uint32_t)ty * (uint32_t)g_w);
       if (g_off + t < cap) {
+        uint32_t v = g_idx;
+        if constexpr (MASKS)
+          v |= ellipse_block_mask(g_mx, g_my, g_cx, g_cy, g_cz, g_thr, (float)((g_x0 + tx) * 16), (float)((g_y0 + ty) * 16)) << kMaskShift;
         tile_keys[g_off + t] = (uint32_t)((g_y0 + ty) * gx + (g_x0 + tx));
-        vals[g_off + t] = g_idx;
+        vals[g_off + t] = v;
       }
     }
   }

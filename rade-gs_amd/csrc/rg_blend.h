@@ -74,4 +74,87 @@ RG_HD float splat_power(float a_x, float b_xy, float cz, float dy) {
   return fmaf(-0.5f, s, -v);
 }
 
+// ---- which 8x4-pixel blocks of a 16x16 tile can a splat reach?  (block lists of the sub-tile entry streams, rg_streams.inc) ----
+// Bit b of the result (block column b & 1, block row b >> 1) is set unless NO pixel centre of the block can pass the blend loop's
+// alpha >= 1/255 test.  The set {alpha can reach 1/255} is the ellipse  cx dx^2 + 2 cy dx dy + cz dy^2 <= M  around the mean,
+// M = -2 thr + slack (thr: skip_threshold(), which already carries 1e-3 of margin in the exponent).  A block row is a slab
+// dy in [va, va + 3]; the ellipse's x-extent over a slab is an interval whose ends are reached either at the ellipse's own
+// x-extreme (when that point lies in the slab) or on the slab line nearest to it:
+//     f+-(t) = (-cy t +- sqrt(cx M - det t^2)) / cx            (roots of the quadratic in dx at dy = t)
+//     x_hi = f+(clamp(t*, a, b)),  x_lo = f-(clamp(-t*, a, b)),  t* = -cy hx / cz,  hx = sqrt(cz M / det),  [a, b] = slab ^ [-hy, hy]
+// and the row's two blocks are kept when that interval reaches their columns: 4 slabs x 2 roots instead of 8 x 4 clamped edge
+// minimisations.  Conservative by construction: slack covers the fp32 rounding of `power` at a pixel (1e-5 of the magnitude of its
+// terms over the tile) plus 1e-2 for this function's own arithmetic (the root moves by < slack / (2 sqrt(disc)) for a relative
+// error of 1e-4 in det, which `regular` guarantees), the discriminant is biased upwards, extents are widened by 0.01 px + 1e-4 hx.
+// Irregular conics (NaN, not positive definite, determinant lost to cancellation) keep every block: the exact per-pixel rule
+// decides, as for any entry of a tile-wide list.  thr > 0: not even the centre reaches 1/255.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RG_SQRT_APPROX(x) __builtin_amdgcn_sqrtf(x)
+#define RG_RCP_APPROX(x) __builtin_amdgcn_rcpf(x)
+#else
+#define RG_SQRT_APPROX(x) sqrtf(x)
+#define RG_RCP_APPROX(x) (1.0f / (x))
+#endif
+// The test in three pieces so that callers which visit several tiles of one splat share the work: the set-up once per splat
+// (U, V: the largest |dx|, |dy| of any pixel centre that will be asked about), the x-extent once per slab, two compares per block.
+struct EllipseSetup {
+  int kind;   // 0: reaches nothing (thr > 0); 1: irregular, keep every block; 2: the fields below are valid
+  float cy, det, cxM, icx, hx, hy, tstar, eps;
+};
+RG_HD EllipseSetup ellipse_setup(float mx, float my, float cx, float cy, float cz, float thr, float U, float V) {
+  EllipseSetup e;
+  e.cy = cy; e.det = 0.f; e.cxM = 0.f; e.icx = 0.f; e.hx = 0.f; e.hy = 0.f; e.tstar = 0.f; e.eps = 0.f;
+  if (thr > 0.f) { e.kind = 0; return e; }
+  const float cxcz = cx * cz;
+  const float det = cxcz - cy * cy;
+  const float chk = ((mx + my) + (cx + cy)) + ((cz + thr) + (U + V));   // NaN / inf - inf anywhere -> NaN
+  const bool regular = (cx > 0.f) && (cz > 0.f) && (det > 1.0e-3f * cxcz) && (chk == chk) && (cxcz < 1.0e30f);
+  if (!regular) { e.kind = 1; return e; }
+  const float terms = fmaf(cx * U, U, fmaf(cz * V, V, 2.0f * fabsf(cy) * U * V));
+  const float M = fmaf(2.0e-5f, terms, fmaf(-2.0f, thr, 1.0e-2f));
+  const float rdet = RG_RCP_APPROX(det), icz = RG_RCP_APPROX(cz);
+  e.kind = 2;
+  e.det = det;
+  e.icx = RG_RCP_APPROX(cx);
+  e.cxM = cx * M * 1.000001f;
+  e.hy = RG_SQRT_APPROX(e.cxM * rdet) * 1.0002f;
+  e.hx = RG_SQRT_APPROX(cz * M * rdet) * 1.0002f;
+  e.tstar = -cy * e.hx * icz;
+  e.eps = fmaf(1.0e-4f, e.hx, 1.0e-2f);
+  return e;
+}
+// x-extent [xlo, xhi] (relative to the mean, already widened by eps) of the ellipse over the slab dy in [va, va + 3]; false: misses it
+RG_HD bool ellipse_slab(const EllipseSetup& e, float va, float& xlo, float& xhi) {
+  const float vb = va + 3.f;
+  const bool hit = (va <= e.hy) && (vb >= -e.hy);
+  const float a = fmaxf(va, -e.hy), b = fminf(vb, e.hy);
+  const float tp = fminf(fmaxf(e.tstar, a), b), tm = fminf(fmaxf(-e.tstar, a), b);
+  const float dp = fmaxf(fmaf(-e.det * tp, tp, e.cxM), 0.f), dm = fmaxf(fmaf(-e.det * tm, tm, e.cxM), 0.f);
+  const float hi = (RG_SQRT_APPROX(dp) - e.cy * tp) * e.icx, lo = (-RG_SQRT_APPROX(dm) - e.cy * tm) * e.icx;
+  xhi = ((tp == e.tstar) ? e.hx : hi) + e.eps;
+  xlo = ((tm == -e.tstar) ? -e.hx : lo) - e.eps;
+  return hit;
+}
+// the two blocks of a block row: pixel columns [ua, ua + 7] and [ua + 8, ua + 15] relative to the mean
+RG_HD uint32_t ellipse_cols(bool hit, float xlo, float xhi, float ua) {
+  const bool c0 = hit && (xlo <= ua + 7.f) && (xhi >= ua), c1 = hit && (xlo <= ua + 15.f) && (xhi >= ua + 8.f);
+  return (c0 ? 1u : 0u) | (c1 ? 2u : 0u);
+}
+RG_HD uint32_t ellipse_tile_mask(const EllipseSetup& e, float ua, float va0) {
+  if (e.kind != 2) return e.kind == 1 ? 0xFFu : 0u;
+  uint32_t mask = 0u;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    float xlo, xhi;
+    const bool hit = ellipse_slab(e, va0 + (float)(4 * r), xlo, xhi);
+    mask |= ellipse_cols(hit, xlo, xhi, ua) << (2 * r);
+  }
+  return mask;
+}
+RG_HD uint32_t ellipse_block_mask(float mx, float my, float cx, float cy, float cz, float thr, float tile_x0, float tile_y0) {
+  const float ua = tile_x0 - mx, va0 = tile_y0 - my;
+  const float U = fmaxf(fabsf(ua), fabsf(ua + 15.f)), V = fmaxf(fabsf(va0), fabsf(va0 + 15.f));
+  return ellipse_tile_mask(ellipse_setup(mx, my, cx, cy, cz, thr, U, V), ua, va0);
+}
+
 }  // namespace rg

@@ -105,6 +105,8 @@ struct BinState {
 // entry j of this round).  The chunks of (tile t, block b) start at chunk index
 //     8 * ((range.x[t] >> 4) + t) + b * ceil(n_t / 16)
 // which needs no counting pass: sum_{t' < t} ceil(n_t'/16) <= (range.x[t] >> 4) + t.
+constexpr int kMaskShift = 24;                       // entry streams: instance value = Gaussian index | block mask << 24 while it is sorted
+constexpr uint32_t kGidMask = (1u << kMaskShift) - 1u;
 constexpr int kBlocksPerTile = 8;
 constexpr int kChunkWords = 48;   // 16 x uint2 + 16 x u32
 inline size_t stream_chunk_capacity(size_t R, size_t tiles) { return (size_t)kBlocksPerTile * ((R >> 4) + tiles + 1); }

@@ -1,5 +1,7 @@
 #!/bin/bash
+# SQ counters of the kernels whose name contains $1 (default: blend), three counter sets in three runs
 set -u
+export PMC_FILTER=${1:-blend}
 mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
 cd /tmp
@@ -17,6 +19,6 @@ for run in ['sq1','sq2','sq3']:
     agg=collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(fs[0])):
         k=r['Kernel_Name']
-        if 'blend' in k: agg[k.split('(')[0][-44:]][r['Counter_Name']].append(float(r['Counter_Value']))
+        if os.environ.get('PMC_FILTER','blend') in k: agg[k.split('(')[0][-44:]][r['Counter_Name']].append(float(r['Counter_Value']))
     for k,v in agg.items(): print(run,k,{c: round(sum(x)/len(x)) for c,x in v.items()})
 PY

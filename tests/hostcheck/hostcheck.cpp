@@ -93,6 +93,32 @@ void hc_preprocess_bwd(int P, int deg, int M, const float* means, const float* s
   }
 }
 
+// Block masks of the sub-tile entry streams: ellipse_block_mask() against the brute-force truth "some pixel centre of the block
+// passes the forward blend loop's own test" (power <= 0 and min(0.99, op exp_spec(power)) >= 1/255, evaluated exactly as the
+// kernels do).  rec: [n][6] = mx, my, cx, cy, cz, op; the tile's first pixel is (tx0, ty0).  out: [n][2] = mask, truth.
+void hc_block_masks(int n, const float* rec, float tx0, float ty0, unsigned* out) {
+  for (int i = 0; i < n; i++) {
+    const float* r = rec + 6 * (size_t)i;
+    const float mx = r[0], my = r[1], cx = r[2], cy = r[3], cz = r[4], op = r[5];
+    out[2 * i] = ellipse_block_mask(mx, my, cx, cy, cz, skip_threshold(op), tx0, ty0);
+    unsigned truth = 0;
+    for (int b = 0; b < 8; b++) {
+      bool any = false;
+      for (int py = 0; py < 4 && !any; py++)
+        for (int px = 0; px < 8 && !any; px++) {
+          const float x = tx0 + (b & 1) * 8 + px, y = ty0 + (b >> 1) * 4 + py;
+          const float dx = mx - x, dy = my - y;
+          const float power = splat_power((cx * dx) * dx, cy * dx, cz, dy);
+          if (power > 0.0f) continue;
+          const float alpha = fminf(0.99f, op * exp_spec(power));
+          if (!(alpha < 1.0f / 255.0f)) any = true;
+        }
+      if (any) truth |= 1u << b;
+    }
+    out[2 * i + 1] = truth;
+  }
+}
+
 float hc_exp_spec(float x) { return exp_spec(x); }
 float hc_splat_power(float cx, float cy, float cz, float dx, float dy) { return splat_power((cx * dx) * dx, cy * dx, cz, dy); }
 float hc_skip_threshold(float op) { return skip_threshold(op); }

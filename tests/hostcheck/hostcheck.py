@@ -94,3 +94,11 @@ def preprocess_bwd(scene, radii, clamped, op_combined, acc, use_sh=True, cov3D=N
                         ctypes.c_float(s.tanfovy), ctypes.c_float(s.kernel_size), ctypes.c_float(1.0), _p(_f(acc)), _p(out),
                         _p(dsh) if shs is not None else None)
     return out, dsh
+
+
+def block_masks(rec, tx0, ty0):
+    """rec [n,6] = mx,my,cx,cy,cz,op -> (mask of ellipse_block_mask, brute-force truth), uint32 [n] each."""
+    rec = _f(rec)
+    out = np.zeros((rec.shape[0], 2), np.uint32)
+    lib().hc_block_masks(ctypes.c_int(rec.shape[0]), _p(rec), ctypes.c_float(tx0), ctypes.c_float(ty0), _p(out))
+    return out[:, 0], out[:, 1]
