@@ -211,6 +211,8 @@ void radegs_profile_enable(int on);
 /* stage >= 0: record events for that stage only (each recorded stage boundary costs ~10 us of stream bubble, so a timed
  * run should select just the kernel it reports); -1: all stages. */
 void radegs_profile_select(int stage);
+/* With a selected stage: time only every `every`-th launch of it (an event pair costs ~10 us of stream bubble; 1 = every launch). */
+void radegs_profile_stride(int every);
 int radegs_profile_num_stages(void);
 const char* radegs_profile_stage_name(int i);
 int radegs_profile_collect(float* ms_total, int* count, int n);

@@ -76,7 +76,7 @@ class RadegsIntegrateArgs(ctypes.Structure):
 # every symbol include/radegs.h declares
 EXPORTED_SYMBOLS = ("radegs_forward", "radegs_backward", "radegs_mark_visible", "radegs_integrate", "radegs_sh_grad_from_views", "radegs_geometry_bytes", "radegs_image_bytes",
                     "radegs_binning_bytes", "radegs_debug_export", "radegs_last_error", "radegs_version", "radegs_profile_enable",
-                    "radegs_profile_select", "radegs_binning_stats", "radegs_profile_num_stages", "radegs_profile_stage_name", "radegs_profile_collect",
+                    "radegs_profile_select", "radegs_profile_stride", "radegs_binning_stats", "radegs_profile_num_stages", "radegs_profile_stage_name", "radegs_profile_collect",
                     # fused pre/post steps (bound in graphics_utils.py / gaussian_model_ops.py)
                     "radegs_normals_forward", "radegs_normals_backward", "radegs_normal_loss_scratch_bytes",
                     "radegs_normal_loss_forward", "radegs_normal_loss_backward", "radegs_normals_last_error",
@@ -160,6 +160,8 @@ def library():
         L.radegs_profile_enable.argtypes = [ctypes.c_int]
         L.radegs_profile_select.restype = None
         L.radegs_profile_select.argtypes = [ctypes.c_int]
+        L.radegs_profile_stride.restype = None
+        L.radegs_profile_stride.argtypes = [ctypes.c_int]
         L.radegs_profile_num_stages.restype = ctypes.c_int
         L.radegs_profile_stage_name.restype = ctypes.c_char_p
         L.radegs_profile_stage_name.argtypes = [ctypes.c_int]
@@ -509,15 +511,16 @@ def binning_stats(reset=False):
     return int(calls.value), int(misses.value)
 
 
-def profile_enable(on=True, only=None):
+def profile_enable(on=True, only=None, every=1):
     """Per-stage HIP-event timing on the launch stream.  `only` = a stage name: record that stage alone (every recorded stage
-    boundary costs ~10 us of stream bubble, so a timed run selects just the kernel it reports)."""
+    boundary costs ~10 us of stream bubble, so a timed run selects just the kernel it reports), `every` = n: every n-th launch."""
     L = library()
     sel = -1
     if only is not None:
         names = [L.radegs_profile_stage_name(i).decode() for i in range(L.radegs_profile_num_stages())]
         sel = names.index(only)
     L.radegs_profile_select(sel)
+    L.radegs_profile_stride(int(every) if only is not None else 1)
     L.radegs_profile_enable(int(bool(on)))
 
 
