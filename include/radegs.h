@@ -131,9 +131,6 @@ typedef struct RadegsBwdArgs {
    * written): the SH gradient is the outer product basis(dir) x this vector and can be rebuilt with
    * radegs_sh_grad_from_views -- which is how the view-parallel exchange moves 12 instead of 192 bytes per Gaussian. */
   float* dL_drgb_clamped;
-  /* nonzero: the buffer `accum_alloc` returns is ALL ZEROS on entry (a buffer the caller keeps between calls).  The call then
-   * skips its own clear and hands the buffer back all zeros: the kernel that consumes a Gaussian's sums clears them. */
-  int accum_is_zero;
 } RadegsBwdArgs;
 
 /* `accum_alloc` provides the per-Gaussian accumulation scratch (64 or 128 B per Gaussian). */

@@ -1406,8 +1406,7 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
 struct PreBwdArgs {
   int P, D, M;
   const float* means3D; const float* scales; const float* rotations; const float* cov3D_precomp; const float* shs;
-  const int* radii; const float4* splat_a; const uint8_t* clamped; float* acc; int rec;
-  int clear_acc;   // the accumulator is a buffer the caller keeps: hand every line read back as zeros (RadegsBwdArgs::accum_is_zero)
+  const int* radii; const float4* splat_a; const uint8_t* clamped; const float* acc; int rec;
   CamArgs cam;
   float* dL_dmean2D; float* dL_dcolor; float* dL_dopacity; float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale;
   float* dL_drot;
@@ -1464,10 +1463,8 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
       const Camera cam = load_camera(a.cam);
       SplatAcc acc;
       {
-        float4* r = reinterpret_cast<float4*>(a.acc + i * a.rec);
+        const float4* r = reinterpret_cast<const float4*>(a.acc + i * a.rec);
         const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.clear_acc) { r[0] = z4; r[1] = z4; r[2] = z4; r[3] = z4; }
         acc.dcolor[0] = r0.x; acc.dcolor[1] = r0.y; acc.dcolor[2] = r0.z; acc.dts = r0.w;
         acc.drp[0] = r1.x; acc.drp[1] = r1.y; acc.dnrm[0] = r1.z; acc.dnrm[1] = r1.w;
         acc.dnrm[2] = r2.x; acc.dmean2D[0] = r2.y; acc.dmean2D[1] = r2.z; acc.dmean2D[2] = r2.w;
@@ -1475,7 +1472,6 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
         if (a.rec == 32) {
           const float4 r4 = r[4], r5 = r[5];
           const float r6 = r[6].x;
-          if (a.clear_acc) { r[4] = z4; r[5] = z4; r[6] = z4; }
           acc.dvp[0] = r4.x; acc.dvp[1] = r4.y; acc.dvp[2] = r4.z; acc.dcp[0] = r4.w;
           acc.dcp[1] = r5.x; acc.dcp[2] = r5.y; acc.dcp[3] = r5.z; acc.dcp[4] = r5.w; acc.dcp[5] = r6;
         } else {

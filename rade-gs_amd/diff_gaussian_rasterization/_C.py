@@ -57,7 +57,7 @@ class RadegsBwdArgs(ctypes.Structure):
                 ("dL_dmean3D", ctypes.c_void_p), ("dL_dcov3D", ctypes.c_void_p), ("dL_dsh", ctypes.c_void_p),
                 ("dL_dscale", ctypes.c_void_p), ("dL_drot", ctypes.c_void_p),
                 ("require_coord", ctypes.c_int), ("require_depth", ctypes.c_int), ("debug", ctypes.c_int),
-                ("dL_drgb_clamped", ctypes.c_void_p), ("accum_is_zero", ctypes.c_int)]
+                ("dL_drgb_clamped", ctypes.c_void_p)]
 
 
 class RadegsIntegrateArgs(ctypes.Structure):
@@ -221,54 +221,6 @@ class _Resizable:
         self.cb = None
 
 
-class _KeptAccumulator:
-    """The backward's per-Gaussian accumulation scratch (64 / 128 B per Gaussian), kept between calls per (device, stream):
-    `radegs_backward` is told it arrives all zeros (`accum_is_zero`) and hands it back all zeros -- the kernel that consumes a
-    Gaussian's sums clears them -- so no 64 MB memset per step.  One call at a time per key (`busy`); a failed call drops the
-    buffer.  RADEGS_KEEP_ACCUMULATOR=0 restores a fresh, cleared buffer per call."""
-    enabled = os.environ.get("RADEGS_KEEP_ACCUMULATOR", "1") != "0"
-    _store = {}
-    _lock = threading.Lock()
-
-    def __init__(self, device):
-        self.key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
-        self.device = device
-        self.error = None
-        self.tensor = None
-        self.cb = None
-        self.ok = False
-        with self._lock:
-            ent = self._store.get(self.key)
-            if ent is None:
-                ent = self._store[self.key] = {"t": None, "busy": False}
-            if ent["busy"]:
-                return
-            ent["busy"] = True
-        self.ok = True
-        self.ent = ent
-
-        def _cb(_user, nbytes):
-            try:
-                t = self.ent["t"]
-                if t is None or t.numel() < int(nbytes):
-                    t = self.ent["t"] = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)
-                self.tensor = t
-                return t.data_ptr()
-            except Exception as ex:  # surfaces as RADEGS_ERR_ALLOC
-                self.error = ex
-                return 0
-
-        self.cb = _ALLOC_FN(_cb)
-
-    def release(self, failed=False):
-        self.cb = None
-        if self.ok:
-            with self._lock:
-                if failed:
-                    self.ent["t"] = None
-                self.ent["busy"] = False
-
-
 _ZERO_MAPS = {}
 
 
@@ -382,23 +334,17 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         gb, bb, ib = geomBuffer.contiguous(), binningBuffer.contiguous(), imageBuffer.contiguous()
         if not sc is None and rot is None:
             raise RuntimeError("scales given without rotations")
-        acc = _KeptAccumulator(dev) if (_KeptAccumulator.enabled and not KEEP_ACC) else None
-        kept = acc is not None and acc.ok
-        if not kept:
-            acc = _Resizable(dev)
+        acc = _Resizable(dev)
         a = RadegsBwdArgs(P, int(degree), M, int(R), W, H, _ptr(bg), _ptr(m3), _ptr(shs), _ptr(col), _ptr(al), _ptr(sc), _ptr(rot),
                           _ptr(cov), _ptr(vm), _ptr(pm), _ptr(cp), float(scale_modifier), float(tan_fovx), float(tan_fovy),
                           float(kernel_size), _ptr(rad), _ptr(nm), _ptr(gb) if gb.numel() else None, _ptr(bb) if bb.numel() else None,
                           _ptr(ib) if ib.numel() else None, _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(g[4]), _ptr(g[5]),
                           _ptr(g[6]), _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
                           _ptr(dL_dsh) if (M and dL_dsh is not None) else None, _ptr(dL_dscales), _ptr(dL_drotations),
-                          int(bool(require_coord)), int(bool(require_depth)), int(bool(debug)), _ptr(drgb), int(kept))
+                          int(bool(require_coord)), int(bool(require_depth)), int(bool(debug)), _ptr(drgb))
         with torch.cuda.device(dev):
             rc = L.radegs_backward(ctypes.byref(a), acc.cb, None, _stream(dev))
-        if kept:
-            acc.release(failed=rc < 0 or acc.error is not None)
-        else:
-            acc.release()
+        acc.release()
         if acc.error is not None:
             raise acc.error
         _check(rc, "radegs_backward")

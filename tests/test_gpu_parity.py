@@ -371,39 +371,15 @@ def test_speculative_binning_matches_exact_path():
 
 
 @pytest.mark.gpu
-def test_kept_accumulator_and_zero_maps():
-    """The backward's accumulation scratch is kept between calls and handed back all zeros by the kernel that consumes it
-    (RadegsBwdArgs::accum_is_zero), and maps the call does not produce are cached zero tensors: back-to-back calls that switch the
-    record size (coord map on / off) must give the same gradients as the path with a fresh, cleared buffer per call."""
-    import diff_gaussian_rasterization._C as C
+def test_unproduced_maps_are_zero_call_after_call():
+    """Maps a mode does not produce are cached zero tensors (handed out again while nobody wrote to them): they must be zeros on
+    every call, also after the mode changed in between, and a caller that writes into one must not poison the next call."""
     from gpu_util import HipRun
-    assert C._KeptAccumulator.enabled
-    for rnd, (coord, depth) in enumerate([(False, True), (True, True), (False, True), (True, False)]):
-        s = make_scene(5000, 203, 131, sh_degree=2, mu_px=2.5, seed=70 + rnd, kernel_size=0.1, require_coord=coord, require_depth=depth, pose="random")
-        g = upstream_grads(s, 70 + rnd)
-        def run():
-            h = HipRun(s, _dev())
-            outs = h.forward()
-            return outs, h.backward(g)
-        outs, kept1 = run()
-        _, kept2 = run()
-        C.KEEP_ACC = True   # the test hook also selects a fresh buffer that the call clears itself
-        try:
-            _, fresh = run()
-        finally:
-            C.KEEP_ACC = False
-        for k, c in fresh.items():
-            if c is None:
-                continue
-            scale = float(np.abs(c).max()) + 1e-30
-            assert float(np.abs(kept1[k] - c).max()) <= 2e-4 * scale and float(np.abs(kept2[k] - c).max()) <= 2e-4 * scale, k
-        torch.cuda.synchronize()
-        for ent in C._KeptAccumulator._store.values():
-            assert ent["t"] is None or not bool(ent["t"].any()), "the kept accumulator must come back all zeros"
-            assert not ent["busy"]
-        # maps the mode does not produce are zeros -- and stay zeros call after call
-        color, radii, co, mco, de, mde, alpha, normal = outs
+    for rnd, (coord, depth) in enumerate([(False, True), (True, True), (False, True), (True, False), (False, True)]):
+        s = make_scene(3000, 203, 131, sh_degree=1, mu_px=2.5, seed=70 + rnd, kernel_size=0.1, require_coord=coord, require_depth=depth, pose="random")
+        color, radii, co, mco, de, mde, alpha, normal = HipRun(s, _dev()).forward()
         if not coord:
             assert not bool(co.any()) and not bool(mco.any())
+            co.detach().add_(1.0)   # a caller scribbling over its map: the cache must notice (version counter) and not reuse it
         if not depth:
             assert not bool(de.any()) and not bool(mde.any())
