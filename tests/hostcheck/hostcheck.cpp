@@ -119,6 +119,46 @@ void hc_block_masks(int n, const float* rec, float tx0, float ty0, unsigned* out
   }
 }
 
+// The same question asked the way emit_instances_kernel<true> asks it: one set-up per splat for its whole tile rectangle
+// [tx0, tx1) x [ty0, ty1) (tile units), the slab extents of a tile row shared by its tiles.  out: [n][tiles][2] = mask, truth with
+// tiles = (tx1-tx0)*(ty1-ty0), rows outer.
+void hc_block_masks_rect(int n, const float* rec, int tx0, int ty0, int tx1, int ty1, unsigned* out) {
+  const int tw = tx1 - tx0, th = ty1 - ty0;
+  for (int i = 0; i < n; i++) {
+    const float* r = rec + 6 * (size_t)i;
+    const float mx = r[0], my = r[1], cx = r[2], cy = r[3], cz = r[4], op = r[5];
+    const float U = fmaxf(fabsf((float)(tx0 * 16) - mx), fabsf((float)(tx1 * 16 - 1) - mx));
+    const float V = fmaxf(fabsf((float)(ty0 * 16) - my), fabsf((float)(ty1 * 16 - 1) - my));
+    const EllipseSetup e = ellipse_setup(mx, my, cx, cy, cz, skip_threshold(op), U, V);
+    for (int y = ty0; y < ty1; y++) {
+      float xl[4] = {0, 0, 0, 0}, xh[4] = {0, 0, 0, 0};
+      bool hit[4] = {false, false, false, false};
+      if (e.kind == 2)
+        for (int q = 0; q < 4; q++) hit[q] = ellipse_slab(e, (float)(y * 16 + 4 * q) - my, xl[q], xh[q]);
+      for (int x = tx0; x < tx1; x++) {
+        unsigned mask = e.kind == 1 ? 0xFFu : 0u;
+        if (e.kind == 2)
+          for (int q = 0; q < 4; q++) mask |= ellipse_cols(hit[q], xl[q], xh[q], (float)(x * 16) - mx) << (2 * q);
+        unsigned truth = 0;
+        for (int b = 0; b < 8; b++) {
+          bool any = false;
+          for (int py = 0; py < 4 && !any; py++)
+            for (int px = 0; px < 8 && !any; px++) {
+              const float X = (float)(x * 16 + (b & 1) * 8 + px), Y = (float)(y * 16 + (b >> 1) * 4 + py);
+              const float dx = mx - X, dy = my - Y;
+              const float power = splat_power((cx * dx) * dx, cy * dx, cz, dy);
+              if (power > 0.0f) continue;
+              if (!(fminf(0.99f, op * exp_spec(power)) < 1.0f / 255.0f)) any = true;
+            }
+          if (any) truth |= 1u << b;
+        }
+        unsigned* o = out + 2 * (((size_t)i * th + (y - ty0)) * tw + (x - tx0));
+        o[0] = mask; o[1] = truth;
+      }
+    }
+  }
+}
+
 float hc_exp_spec(float x) { return exp_spec(x); }
 float hc_splat_power(float cx, float cy, float cz, float dx, float dy) { return splat_power((cx * dx) * dx, cy * dx, cz, dy); }
 float hc_skip_threshold(float op) { return skip_threshold(op); }

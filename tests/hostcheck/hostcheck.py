@@ -102,3 +102,12 @@ def block_masks(rec, tx0, ty0):
     out = np.zeros((rec.shape[0], 2), np.uint32)
     lib().hc_block_masks(ctypes.c_int(rec.shape[0]), _p(rec), ctypes.c_float(tx0), ctypes.c_float(ty0), _p(out))
     return out[:, 0], out[:, 1]
+
+
+def block_masks_rect(rec, tx0, ty0, tx1, ty1):
+    """as block_masks, asked per splat for a whole tile rectangle the way the instance emission does -> [n, tiles] mask, truth."""
+    rec = _f(rec)
+    tiles = (tx1 - tx0) * (ty1 - ty0)
+    out = np.zeros((rec.shape[0], tiles, 2), np.uint32)
+    lib().hc_block_masks_rect(ctypes.c_int(rec.shape[0]), _p(rec), ctypes.c_int(tx0), ctypes.c_int(ty0), ctypes.c_int(tx1), ctypes.c_int(ty1), _p(out))
+    return out[:, :, 0], out[:, :, 1]

@@ -49,3 +49,21 @@ def test_block_mask_edge_cases():
                     [3.2, 1.7, 4, 0, 4, 0.9]], np.float32)    # tiny splat inside block 0 only
     mask, truth = hc.block_masks(rec, 0.0, 0.0)
     assert list(mask) == [0, 255, 255, 255, 0, 1] and int(truth[5]) == 1 and int(truth[0]) == 0 and int(truth[4]) == 0
+
+
+@pytest.mark.parametrize("sig_lo,sig_hi,aspect_hi", [(0.5, 8.0, 6.0), (3.0, 40.0, 30.0)])
+def test_block_masks_as_the_emission_asks(sig_lo, sig_hi, aspect_hi):
+    """One set-up per splat for its whole 3x4-tile rectangle (slack from the rectangle's extent), slab extents shared by the tiles
+    of a tile row -- the call pattern of emit_instances_kernel<true>."""
+    rng = np.random.default_rng(7)
+    n = 15000
+    cx, cy, cz = _conics(n, rng, sig_lo, sig_hi, aspect_hi, 0.3)
+    tx0, ty0, tx1, ty1 = 50, 20, 53, 24
+    mx = rng.uniform(tx0 * 16 - 20, tx1 * 16 + 20, n).astype(np.float32)
+    my = rng.uniform(ty0 * 16 - 20, ty1 * 16 + 20, n).astype(np.float32)
+    op = np.exp(rng.uniform(np.log(1.0 / 300.0), 0.0, n)).astype(np.float32)
+    mask, truth = hc.block_masks_rect(np.stack([mx, my, cx, cy, cz, op], 1), tx0, ty0, tx1, ty1)
+    assert not (truth & ~mask).any()
+    kept = int(np.unpackbits(mask.astype(np.uint8)).sum()), int(np.unpackbits(truth.astype(np.uint8)).sum())
+    print("rect pattern: blocks kept %d, reachable %d" % kept)
+    assert kept[0] <= 1.3 * kept[1] + 100

@@ -383,3 +383,16 @@ def test_unproduced_maps_are_zero_call_after_call():
             co.detach().add_(1.0)   # a caller scribbling over its map: the cache must notice (version counter) and not reuse it
         if not depth:
             assert not bool(de.any()) and not bool(mde.any())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("coord,depth", [(False, True), (True, True)])
+def test_big_splats_through_the_entry_streams(coord, depth, monkeypatch):
+    """Splats of more than 16 tiles are emitted by the whole wave (one lane per tile); with entry streams forced, that path computes
+    the block masks too (one ellipse_block_mask per lane from the broadcast record)."""
+    monkeypatch.setenv("RADEGS_STREAMS", "1")
+    s = make_scene(1500, 203, 131, sh_degree=1, mu_px=14.0, seed=93, kernel_size=0.1, require_coord=coord, require_depth=depth, pose="random",
+                   low_opacity=True)
+    o, _ = check_forward(s)
+    assert int((o.get("tiles_touched") > 16).sum()) > 200
+    check_backward(s, o, seed=93)
