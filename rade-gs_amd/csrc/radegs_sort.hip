@@ -112,10 +112,6 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const uint32_t* _
   __shared__ uint32_t lds_k[BLOCK_ITEMS];     // the block's items reordered by digit (stable), so that the global
   __shared__ uint32_t lds_v[BLOCK_ITEMS];     // writes below go out in contiguous per-digit runs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  digit_base[tid] = block256_exclusive(totals[tid], scan_tmp) + hist[(size_t)tid * nblocks + blockIdx.x];
-#pragma unroll
-  for (int w = 0; w < 4; w++) wave_cnt[w][tid] = 0;
-  __syncthreads();
   const uint32_t block0 = blockIdx.x * (uint32_t)BLOCK_ITEMS;
   const uint32_t run0 = block0 + wave * (uint32_t)WAVE_ITEMS;  // this wave's contiguous run
   // the wave's whole run goes to registers first: all 2 x ITEMS loads are in flight together, the keys serve both phases
@@ -130,6 +126,10 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const uint32_t* _
     const uint32_t i = run0 + r * 64 + lane;
     rv[r] = i < n ? (vals_in ? vals_in[i] : i) : 0u;
   }
+  digit_base[tid] = block256_exclusive(totals[tid], scan_tmp) + hist[(size_t)tid * nblocks + blockIdx.x];
+#pragma unroll
+  for (int w = 0; w < 4; w++) wave_cnt[w][tid] = 0;
+  __syncthreads();
   // ---- phase A: histogram of every wave's run ----
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
@@ -190,7 +190,8 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const uint32_t* _
   }
 }
 
-// ---- inclusive scan of tiles_touched gathered through idx_sorted (reduce, scan the block sums, scan) ----
+// ---- inclusive scan of tiles_touched gathered through idx_sorted: block sums, then a scan in which every block first adds up the
+// sums of the blocks before it (two launches) ----
 constexpr int kScanItems = 16;  // per thread -> 4096 per block
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
   __shared__ uint32_t ws[4];
@@ -241,23 +242,6 @@ __global__ void __launch_bounds__(kSortThreads) gather_block_sums_kernel(const u
   if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-__global__ void __launch_bounds__(kSortThreads) scan_block_sums_kernel(uint32_t* __restrict__ block_sums, uint32_t nblocks) {
-  __shared__ uint32_t carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (uint32_t start = 0; start < nblocks; start += kSortThreads) {
-    const uint32_t i = start + threadIdx.x;
-    const uint32_t v = i < nblocks ? block_sums[i] : 0u;
-    uint32_t total;
-    const uint32_t ex = block_exclusive_scan(v, &total);
-    const uint32_t c = carry;
-    if (i < nblocks) block_sums[i] = c + ex;  // exclusive prefix of the block sums
-    __syncthreads();
-    if (threadIdx.x == 0) carry = c + total;
-    __syncthreads();
-  }
-}
-
 template <bool PACKED>
 __global__ void __launch_bounds__(kSortThreads) gather_scan_kernel(const uint32_t* __restrict__ gathered, uint32_t n,
                                                                    const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ out) {
@@ -270,7 +254,13 @@ __global__ void __launch_bounds__(kSortThreads) gather_scan_kernel(const uint32_
     v[k] = i < n ? (PACKED ? rect_count(gathered[i]) : gathered[i]) : 0u;
     s += v[k];
   }
-  uint32_t run = block_sums[blockIdx.x] + block_exclusive_scan(s, nullptr);
+  // sum of the block sums before this block: every block adds them up itself (a few hundred values) -- cheaper than a
+  // one-workgroup kernel in between, which costs a launch floor of ~5 us
+  uint32_t before = 0;
+  for (uint32_t j = threadIdx.x; j < blockIdx.x; j += kSortThreads) before += block_sums[j];
+  uint32_t before_total;
+  block_exclusive_scan(before, &before_total);
+  uint32_t run = before_total + block_exclusive_scan(s, nullptr);
 #pragma unroll
   for (int k = 0; k < kScanItems; k++) {
     const uint32_t i = base + k;
@@ -360,7 +350,6 @@ hipError_t inclusive_scan_gather_u32(void* temp, size_t temp_bytes, const uint32
   uint32_t* gathered = packed_out ? packed_out : block_sums + ((nblocks + 64) & ~63u);
   if (packed_out) hipLaunchKernelGGL(gather_block_sums_kernel<true>, dim3(nblocks), dim3(kSortThreads), 0, stream, vals, idx, (uint32_t)n, block_sums, gathered);
   else hipLaunchKernelGGL(gather_block_sums_kernel<false>, dim3(nblocks), dim3(kSortThreads), 0, stream, vals, idx, (uint32_t)n, block_sums, gathered);
-  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(kSortThreads), 0, stream, block_sums, nblocks);
   if (packed_out) hipLaunchKernelGGL(gather_scan_kernel<true>, dim3(nblocks), dim3(kSortThreads), 0, stream, gathered, (uint32_t)n, block_sums, out);
   else hipLaunchKernelGGL(gather_scan_kernel<false>, dim3(nblocks), dim3(kSortThreads), 0, stream, gathered, (uint32_t)n, block_sums, out);
   return hipGetLastError();
