@@ -112,6 +112,10 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const uint32_t* _
   __shared__ uint32_t lds_k[BLOCK_ITEMS];     // the block's items reordered by digit (stable), so that the global
   __shared__ uint32_t lds_v[BLOCK_ITEMS];     // writes below go out in contiguous per-digit runs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  digit_base[tid] = block256_exclusive(totals[tid], scan_tmp) + hist[(size_t)tid * nblocks + blockIdx.x];
+#pragma unroll
+  for (int w = 0; w < 4; w++) wave_cnt[w][tid] = 0;
+  __syncthreads();
   const uint32_t block0 = blockIdx.x * (uint32_t)BLOCK_ITEMS;
   const uint32_t run0 = block0 + wave * (uint32_t)WAVE_ITEMS;  // this wave's contiguous run
   // the wave's whole run goes to registers first: all 2 x ITEMS loads are in flight together, the keys serve both phases
@@ -126,10 +130,6 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const uint32_t* _
     const uint32_t i = run0 + r * 64 + lane;
     rv[r] = i < n ? (vals_in ? vals_in[i] : i) : 0u;
   }
-  digit_base[tid] = block256_exclusive(totals[tid], scan_tmp) + hist[(size_t)tid * nblocks + blockIdx.x];
-#pragma unroll
-  for (int w = 0; w < 4; w++) wave_cnt[w][tid] = 0;
-  __syncthreads();
   // ---- phase A: histogram of every wave's run ----
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
