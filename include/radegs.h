@@ -131,6 +131,13 @@ typedef struct RadegsBwdArgs {
    * written): the SH gradient is the outer product basis(dir) x this vector and can be rebuilt with
    * radegs_sh_grad_from_views -- which is how the view-parallel exchange moves 12 instead of 192 bytes per Gaussian. */
   float* dL_drgb_clamped;
+  /* 0 (default): the gradient the reference EXECUTES.  Rasterizer::backward passes `(float4*)dL_dconic` in the position of
+   * BACKWARD::preprocess's `conic_opacity` parameter (rasterizer_impl.cu:568 vs backward.h:94), so computeCov2DCUDA's
+   * `combined_opacity` (backward.cu:179-180) is the accumulated conic gradient dL_dconic[idx].w, not opacity*coef; it scales the
+   * derivative of the opacity-compensation factor w.r.t. the 2D covariance (backward.cu:367-375) and from there dL_dcov3D /
+   * dL_dmeans3D / dL_dscales / dL_drotations.  Negligible (~1e-6 of the conic term) at the reference's default kernel_size = 0.
+   * 1: the derivative the formulas intend (combined_opacity = opacity*coef) -- what an upstream fix would compute. */
+  int opacity_grad_intended;
 } RadegsBwdArgs;
 
 /* `accum_alloc` provides the per-Gaussian accumulation scratch (64 or 128 B per Gaussian). */

@@ -53,6 +53,10 @@ def lib():
         L.oracle_exp_spec.argtypes = [ctypes.c_float]
         L.oracle_set_exp_mode.restype = None
         L.oracle_set_exp_mode.argtypes = [ctypes.c_int]
+        L.oracle_set_opacity_slip.restype = None
+        L.oracle_set_opacity_slip.argtypes = [ctypes.c_int]
+        L.oracle_set_ref_order.restype = None
+        L.oracle_set_ref_order.argtypes = [ctypes.c_int]
         L.oracle_higher_msb.restype = ctypes.c_uint
         L.oracle_higher_msb.argtypes = [ctypes.c_uint]
         L.oracle_kat_mat3.restype = None
@@ -184,6 +188,19 @@ def set_exp_mode(mode):
     """0 = specified exp (default); 1 = libm expf; 2 / 3 = the specification one ulp up / down.  Sensitivity experiments only:
     always restore 0."""
     lib().oracle_set_exp_mode(int(mode))
+
+
+def set_opacity_slip(on):
+    """1 (default): the backward the reference EXECUTES -- `combined_opacity` read from dL_dconic.w because of the argument slip at
+    rasterizer_impl.cu:568 (see radegs_oracle.cpp::g_opacity_slip).  0: the derivative the formulas intend (calculus checks only;
+    always restore 1)."""
+    lib().oracle_set_opacity_slip(int(on))
+
+
+def set_ref_order(on):
+    """1: the blend backward's per-Gaussian sums are formed in fp32 in the order of the compiled reference's host schedule
+    (radegs_oracle.cpp::g_ref_order), for bit-for-bit comparison with oracle/_ref.  Always restore 0."""
+    lib().oracle_set_ref_order(int(on))
 
 
 def higher_msb(n):

@@ -8,10 +8,18 @@
 // and bench.py's cpu_baseline leg may load it.  The product (rade-gs_amd/) never links,
 // imports or falls back to anything in oracle/.
 //
-// PARITY STATUS: "parity unpinned".  The reference ships no test, golden vector or
-// fixture for this path, it is CUDA + un-vendored glm and cannot be
-// built in this environment, so the oracle is pinned only by (a) analytic known-answer
-// cases derived from the cited code, (b) a float64 finite-difference / PyTorch-autograd
+// PARITY STATUS: PINNED to the reference's own code run here.  The reference ships no test,
+// golden vector or fixture for this path and its CUDA build cannot run
+// in this image, but its sources compile for the host (oracle/build_ref.py -> oracle/_ref:
+// forward.cu, backward.cu, rasterizer_impl.cu, auxiliary.h unmodified, on a CUDA execution
+// model made of fibers, with a restatement of the un-vendored glm subset).  This oracle
+// equals that build BIT FOR BIT -- every state array, all 7 maps, all 8 gradients and their
+// intermediate sums, and integrate()'s 6 outputs -- on every scene of tests/test_ref_parity.py,
+// and reproduces the golden vectors that build wrote (tests/golden/g_*.npz).  What the
+// comparison cannot cover is what nothing off-device can: CUDA's expf and nvcc's fma
+// contraction (both sides use exp_spec and -ffp-contract=off; tests/test_oracle_exp_sensitivity.py
+// and tests/test_ref_parity.py::test_fma_contraction_sensitivity measure what they move).
+// Additionally: analytic known-answer cases, a float64 finite-difference and a PyTorch-autograd
 // cross-check of the hand-derived backward (tests/test_oracle_*.py).
 //
 // Numerics: Real=float reproduces the reference's fp32 arithmetic with one rounding per
@@ -51,6 +59,23 @@ static constexpr int TILE = 16;  // BLOCK_X = BLOCK_Y, DGR/cuda_rasterizer/confi
 // expf; 2 / 3 = the specification moved one ulp up / down.  The non-zero modes stand in for "a build whose expf rounds
 // differently" (CUDA's expf is not reproducible off-device) to measure how many thresholded decisions that can flip.
 static int g_exp_mode = 0;
+// g_opacity_slip (oracle_set_opacity_slip): 1 (default) = what the reference EXECUTES.  Rasterizer::backward hands BACKWARD::preprocess
+// `(float4*)dL_dconic` where the callee's parameter list has `conic_opacity` (rasterizer_impl.cu:568 against backward.h:94 /
+// backward.cu:1059), so computeCov2DCUDA's `combined_opacity = conic_opacity[idx].w` (backward.cu:179-180) reads the accumulated
+// conic gradient dL_dconic[idx].w instead of opacity*coef.  The value only enters the derivative of the opacity-compensation
+// factor w.r.t. the 2D covariance (backward.cu:367-375 -> dL_da/db/dc): with kernel_size = 0 (the reference default) that term
+// is ~1e-6 of the conic term, with kernel_size = 0.1 it is not small.  Found by running the reference's own sources on the host
+// (oracle/_ref).  0 = the derivative the formulas intend (used by the finite-difference / autograd checks of the calculus).
+static int g_opacity_slip = 1;
+// g_ref_order (oracle_set_ref_order; fp32 only): 0 (default) = per-Gaussian sums of the blend backward accumulated in double, in
+// any order (deterministic, and what the HIP path's fp32 sums are judged against).  1 = the sums are formed in fp32 in the order
+// the reference's float atomics are applied when its kernel runs one block at a time with the threads of a block advancing
+// batch by batch (tile, batch of 256 list entries from the back, thread rank, entry) -- the schedule of oracle/_ref's host run --
+// so that the oracle's backward can be compared with the compiled reference BIT FOR BIT (tests/test_ref_parity.py).
+static int g_ref_order = 0;
+struct AddLogEntry { uint32_t key, slot; float v; };
+struct AddLog { std::vector<AddLogEntry>* log = nullptr; const double* base = nullptr; uint32_t key = 0; };
+static thread_local AddLog tl_addlog;
 inline float exp_spec_impl(float x);
 inline float exp_spec(float x) {
   if (g_exp_mode == 0) return exp_spec_impl(x);
@@ -849,6 +874,10 @@ template <class R> struct Oracle {
       contributor--;
       if (contributor >= static_cast<uint32_t>(last_contributor)) continue;
       const uint32_t g = point_list[k];
+      if (tl_addlog.log) {   // (batch from the back, thread rank in the 16x16 block, entry in the batch): backward.cu:796-838
+        const uint32_t m = r1 - 1 - k;
+        tl_addlog.key = ((m >> 8) << 16) | (((py % TILE) * TILE + (px % TILE)) << 8) | (m & 255u);
+      }
       const R dx = means2D[2 * g] - pixfx, dy = means2D[2 * g + 1] - pixfy;
       const R cx = conic_opacity[4 * g], cy = conic_opacity[4 * g + 1], cz = conic_opacity[4 * g + 2], co = conic_opacity[4 * g + 3];
       const R power = R(-0.5f) * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
@@ -938,6 +967,7 @@ template <class R> struct Oracle {
   }
   enum { A_COLOR = 0, A_VIEWPT = 3, A_CAMPLANE = 6, A_TS = 12, A_RAYPLANE = 13, A_NORMAL = 15, A_MEAN2D = 18, A_CONIC = 21, A_OPACITY = 24, NACC = 25 };
   static inline void add(double& dst, R v) {
+    if (tl_addlog.log) { tl_addlog.log->push_back({tl_addlog.key, uint32_t(&dst - tl_addlog.base), float(v)}); return; }
     const double dv = static_cast<double>(v);
 #pragma omp atomic
     dst += dv;
@@ -950,7 +980,7 @@ template <class R> struct Oracle {
     V3<R> mean{means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
     R dL_dconic_x = dL_dconic[4 * idx], dL_dconic_y = dL_dconic[4 * idx + 1], dL_dconic_z = dL_dconic[4 * idx + 3];
     const V3<R> dL_dnormal{dL_dnormals[3 * idx], dL_dnormals[3 * idx + 1], dL_dnormals[3 * idx + 2]};
-    const R combined_opacity = conic_opacity[4 * idx + 3];
+    const R combined_opacity = g_opacity_slip ? dL_dconic[4 * idx + 3] : conic_opacity[4 * idx + 3];
     const V2<R> dcp0{dL_dcamera_planes[6 * idx], dL_dcamera_planes[6 * idx + 1]};
     const V2<R> dcp1{dL_dcamera_planes[6 * idx + 2], dL_dcamera_planes[6 * idx + 3]};
     const V2<R> dcp2{dL_dcamera_planes[6 * idx + 4], dL_dcamera_planes[6 * idx + 5]};
@@ -1207,11 +1237,27 @@ template <class R> struct Oracle {
     if (P != 0) {
       const bool COORD = req_coord, DEPTH = req_depth, NORMAL = req_coord || req_depth;
       std::vector<double> A(size_t(P) * NACC, 0.0);
+      if (g_ref_order && sizeof(R) == 4) {
+        std::vector<float> Af(size_t(P) * NACC, 0.0f);
+        std::vector<AddLogEntry> log;
+        for (int tile = 0; tile < gx * gy; tile++) {
+          const int ty = tile / gx, tx = tile % gx;
+          log.clear();
+          tl_addlog.log = &log; tl_addlog.base = A.data();
+          for (int y = ty * TILE; y < std::min((ty + 1) * TILE, H); y++)
+            for (int x = tx * TILE; x < std::min((tx + 1) * TILE, W); x++) render_pixel_bwd(x, y, COORD, DEPTH, NORMAL, gin, A);
+          tl_addlog.log = nullptr;
+          std::stable_sort(log.begin(), log.end(), [](const AddLogEntry& a, const AddLogEntry& b) { return a.key < b.key; });
+          for (const AddLogEntry& e : log) Af[e.slot] += e.v;
+        }
+        for (size_t i = 0; i < A.size(); i++) A[i] = Af[i];
+      } else {
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
       for (int tile = 0; tile < gx * gy; tile++) {
         const int ty = tile / gx, tx = tile % gx;
         for (int y = ty * TILE; y < std::min((ty + 1) * TILE, H); y++)
           for (int x = tx * TILE; x < std::min((tx + 1) * TILE, W); x++) render_pixel_bwd(x, y, COORD, DEPTH, NORMAL, gin, A);
+      }
       }
       for (int i = 0; i < P; i++) {
         const double* a = &A[size_t(i) * NACC];
@@ -1370,6 +1416,8 @@ void oracle_mark_visible(int P, const float* means3D, const float* view, const f
 
 float oracle_exp_spec(float x) { return exp_spec_impl(x); }
 void oracle_set_exp_mode(int mode) { g_exp_mode = mode; }
+void oracle_set_opacity_slip(int on) { g_opacity_slip = on; }
+void oracle_set_ref_order(int on) { g_ref_order = on; }
 unsigned oracle_higher_msb(unsigned n) { return higher_msb(n); }
 // glm column-major KAT hook (forward.cu:126-133): mat3(1..9) * (1,1,1)
 void oracle_kat_mat3(float out[3]) {

@@ -1411,6 +1411,7 @@ struct PreBwdArgs {
   float* dL_dmean2D; float* dL_dcolor; float* dL_dopacity; float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale;
   float* dL_drot;
   float* dL_drgb_clamped;  // optional [P,3]: dL/dRGB with the clamp mask applied (the view-parallel factored exchange)
+  int opacity_grad_intended;  // RadegsBwdArgs::opacity_grad_intended (include/radegs.h)
 };
 
 // 128 Gaussians per block.  The (P,M,3) SH tensor and its gradient are 192-byte rows at SH degree 3: read or
@@ -1504,7 +1505,9 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
       } else {
         cov3d_from_scale_rot(sc3, cam.scale_modifier, rq4, cov);
       }
-      const float op_combined = a.splat_a[4 * i + 1].y;
+      // what the reference's computeCov2DCUDA reads as `conic_opacity[idx].w` is dL_dconic[idx].w (argument slip at
+      // rasterizer_impl.cu:568); the stored opacity*coef only with opacity_grad_intended (include/radegs.h)
+      const float op_combined = a.opacity_grad_intended ? a.splat_a[4 * i + 1].y : acc.dconic[2];
       if (row) {  // rows beyond the active degree stay zero
         const int K = (a.D + 1) * (a.D + 1);
         for (int c = K * 3; c < rowf; c++) row[c] = 0;

@@ -163,7 +163,8 @@ RG_HD void cov3d_bwd(const float s3[3], float mod, const float q[4], const float
 
 // One VISIBLE Gaussian (radius > 0).  cov3D: the covariance the forward used (precomputed or
 // re-derived from scale/quat by the caller with cov3d_from_scale_rot -- same bits as forward).
-// op_combined = opacity*coef as stored by the forward.  sh/dsh may be null (precomputed colours).
+// op_combined: what the reference's kernel reads as `conic_opacity[idx].w` -- by default the conic gradient a.dconic[2] (upstream's
+// argument slip, include/radegs.h::opacity_grad_intended), else opacity*coef as stored by the forward.  sh/dsh may be null (precomputed colours).
 RG_HD void preprocess_bwd(v3 mean, const float* scale3, const float* quat4, const float cov3D[6], float op_combined, int deg,
                           const float* sh, unsigned clamped, const Camera& cam, const SplatAcc& a, float* dsh, SplatBwd& o) {
   Cov2D g;

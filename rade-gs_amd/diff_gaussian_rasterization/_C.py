@@ -57,7 +57,7 @@ class RadegsBwdArgs(ctypes.Structure):
                 ("dL_dmean3D", ctypes.c_void_p), ("dL_dcov3D", ctypes.c_void_p), ("dL_dsh", ctypes.c_void_p),
                 ("dL_dscale", ctypes.c_void_p), ("dL_drot", ctypes.c_void_p),
                 ("require_coord", ctypes.c_int), ("require_depth", ctypes.c_int), ("debug", ctypes.c_int),
-                ("dL_drgb_clamped", ctypes.c_void_p)]
+                ("dL_drgb_clamped", ctypes.c_void_p), ("opacity_grad_intended", ctypes.c_int)]
 
 
 class RadegsIntegrateArgs(ctypes.Structure):
@@ -88,6 +88,10 @@ EXPORTED_SYMBOLS = ("radegs_forward", "radegs_backward", "radegs_mark_visible", 
 _lib = None
 # test hook: when True, the per-Gaussian accumulation scratch of the last backward is kept in LAST_ACC
 KEEP_ACC = False
+# False (default): the backward the reference executes, including its argument slip in the opacity-compensation gradient
+# (include/radegs.h::RadegsBwdArgs.opacity_grad_intended).  True (or RADEGS_OPACITY_GRAD=intended in the environment): the derivative
+# the reference's formulas intend.  Differs only for kernel_size > 0.
+OPACITY_GRAD_INTENDED = os.environ.get("RADEGS_OPACITY_GRAD", "").lower() == "intended"
 LAST_ACC = None
 LAST_POINT_STATE = None
 # Optional allocator for the 8 gradient tensors of the backward: callable(name, shape, dtype, device) -> tensor
@@ -341,7 +345,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                           _ptr(ib) if ib.numel() else None, _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(g[4]), _ptr(g[5]),
                           _ptr(g[6]), _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
                           _ptr(dL_dsh) if (M and dL_dsh is not None) else None, _ptr(dL_dscales), _ptr(dL_drotations),
-                          int(bool(require_coord)), int(bool(require_depth)), int(bool(debug)), _ptr(drgb))
+                          int(bool(require_coord)), int(bool(require_depth)), int(bool(debug)), _ptr(drgb), int(bool(OPACITY_GRAD_INTENDED)))
         with torch.cuda.device(dev):
             rc = L.radegs_backward(ctypes.byref(a), acc.cb, None, _stream(dev))
         acc.release()

@@ -1,7 +1,7 @@
-"""Frozen oracle outputs (tests/golden/*.npz, made by tests/golden/make_golden.py).  CPU tier: the
-oracle must still reproduce them bit-for-bit (fp32, single-threaded accumulation order).  GPU tier:
-the HIP path must match them to the parity bar.  See make_golden.py for why these are oracle
-fixtures and not reference outputs (parity unpinned upstream)."""
+"""Golden vectors produced by the REFERENCE'S OWN CODE (tests/golden/g_*.npz, written by tests/golden/make_golden.py from
+oracle/_ref = the reference's rasterizer sources compiled for the host).  CPU tier: the hand-written oracle reproduces every array
+bit for bit -- also on machines where /root/reference is absent.  GPU tier: the HIP path matches them: exact indices, maps within
+1e-5 / 1e-4, gradients within the parity bar of DESIGN.md section 7."""
 import os
 import sys
 
@@ -18,15 +18,12 @@ def test_oracle_reproduces_golden(case):
     want = np.load(os.path.join(HERE, "golden", case + ".npz"))
     got = make_golden.run(case)
     for k in want.files:
-        a, b = np.asarray(got[k]), want[k]
         if k.startswith("floor_"):
-            assert abs(float(a) - float(b)) <= 1e-3 * float(b) + 1e-12, k
-        elif a.dtype.kind == "f":
-            # -ffp-contract=off + IEEE ops: identical across x86-64 hosts; double accumulators of the
-            # blend backward are order-independent to well below one fp32 ulp
-            assert np.allclose(a, b, rtol=1e-6, atol=1e-7), k
-        else:
-            assert np.array_equal(a, b), k
+            continue
+        a, b = np.asarray(got[k]), want[k]
+        # -ffp-contract=off + IEEE ops + the specified exp on both sides: identical bits (NaN-safe comparison of the raw words)
+        assert a.shape == b.shape and a.dtype == b.dtype, k
+        assert np.array_equal(a.view(np.uint8) if a.dtype.kind == "f" else a, b.view(np.uint8) if b.dtype.kind == "f" else b), k
 
 
 @pytest.mark.gpu
@@ -45,6 +42,9 @@ def test_hip_matches_golden(case):
     assert st[0] == R
     assert np.array_equal(st[8].cpu().numpy(), want["radii"])
     assert np.array_equal(h.export("point_list", torch.int32, R).view(np.uint32), want["point_list"])
+    assert np.array_equal(h.export("tiles_touched", torch.int32, s.means3D.shape[0]).view(np.uint32), want["tiles_touched"])
+    ntiles = ((s.W + 15) // 16) * ((s.H + 15) // 16)
+    assert np.array_equal(h.export("ranges", torch.int32, 2 * ntiles).view(np.uint32), want["ranges"][: 2 * ntiles])
     assert np.array_equal(h.export("n_contrib", torch.int32, 2 * s.H * s.W).view(np.uint32)[: s.H * s.W], want["n_contrib"][: s.H * s.W])
     for k, t in (("color", st[1]), ("coord", st[2]), ("mcoord", st[3]), ("alpha", st[4]), ("normal", st[5]), ("depth", st[6]), ("mdepth", st[7])):
         assert close(t.cpu().numpy(), want[k]).all(), k
@@ -54,5 +54,7 @@ def test_hip_matches_golden(case):
     for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dsh", "dL_dscales", "dL_drotations"):
         b = want[k].reshape(got[k].shape)
         scale = float(np.abs(b).max()) + 1e-30
-        band = ATOL + max(2e-6 * scale, 0.25 * float(want["floor_" + k]))  # see util.grad_noise_floor
+        floor = float(want["floor_" + k])            # see util.grad_noise_floor; NaN: no float64 twin for this scene (DESIGN.md section 7:
+        floor = 4e-5 * scale if floor != floor else floor   # |oracle32 - oracle64| is ~4e-5 of each tensor's scale)
+        band = ATOL + max(2e-6 * scale, 0.25 * floor)
         assert close(got[k], b, atol=band, rtol=1e-3).all(), k

@@ -1,0 +1,253 @@
+"""Pins the oracle to the REFERENCE ITSELF: oracle/_ref is the reference's own forward.cu / backward.cu / rasterizer_impl.cu /
+auxiliary.h, compiled for the host by oracle/build_ref.py (sources read from /root/reference where they lie; a CUDA execution
+model on fibers, oracle/ref_shim/cuda_on_host.h, stands in for nvcc + runtime + CUB; oracle/ref_shim/glm restates the un-vendored
+glm subset).  Every test drives CudaRasterizer::Rasterizer::forward / backward / integrate / markVisible -- the reference's own
+orchestration, kernels and device functions -- and demands BIT-FOR-BIT equality with the hand-written oracle:
+
+  forward:   every state array (per-Gaussian geometry, sort keys, point_list, ranges, both n_contrib planes, accumulators) and
+             all 7 maps;
+  backward:  all 8 returned gradients + the 9 intermediate per-Gaussian sums, with the oracle summing in fp32 in the order the
+             host schedule applies the reference's atomics (oracle.set_ref_order);
+  integrate: all 6 outputs.
+
+Both sides run with -ffp-contract=off and the specified exponential (the two things a CUDA build does differently and nothing
+off-device can reproduce: nvcc's fma contraction and CUDA's expf; test_fma_contraction_sensitivity / test_oracle_exp_sensitivity
+measure what they can move).  These tests run where /root/reference exists (the build container); on the GPU box the vectors this
+library produced (tests/golden/g_*.npz, make_golden.py) are what the HIP path is compared with."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from oracle import ref
+from synth_scene import make_scene, upstream_grads
+from util import cov3d_of, oracle_backward, oracle_for
+
+pytestmark = pytest.mark.skipif(not ref.available(), reason="reference sources (/root/reference) and prebuilt oracle/_ref both absent")
+
+GEOM = ["depths", "camera_planes", "ray_planes", "ts", "normals", "means2D", "view_points", "cov3D", "conic_opacity", "rgb"]
+INTS = ["radii", "tiles_touched", "point_offsets", "clamped", "keys_sorted", "point_list", "ranges", "n_contrib"]
+IMG = ["accum_coord", "accum_depth", "normal_length"]
+SUMS = ["dL_dcolors", "dL_dview_points", "dL_dcamera_planes", "dL_dts", "dL_dray_planes", "dL_dnormals", "dL_dmeans2D", "dL_dconic"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(autouse=True)
+def _same_exponential_and_order():
+    ref.set_exp("spec")
+    ref.set_num_threads(1)
+    orc.set_ref_order(1)
+    yield
+    orc.set_ref_order(0)
+    ref.set_exp("libm")
+
+
+def ref_for(s, colors=None, cov3D=None, scale_modifier=1.0, fma=False):
+    kw = dict(bg=s.bg, means3D=s.means3D, opacities=s.opacities, viewmatrix=s.viewmatrix, projmatrix=s.projmatrix, campos=s.campos,
+              tanfovx=s.tanfovx, tanfovy=s.tanfovy, image_height=s.H, image_width=s.W, sh_degree=s.sh_degree, kernel_size=s.kernel_size,
+              require_coord=s.require_coord, require_depth=s.require_depth, scale_modifier=scale_modifier, fma=fma)
+    if colors is None:
+        kw["shs"] = s.shs
+    else:
+        kw["colors_precomp"] = colors
+    if cov3D is None:
+        kw["scales"], kw["rotations"] = s.scales, s.rotations
+    else:
+        kw["cov3D_precomp"] = cov3D
+    return ref.Ref(**kw)
+
+
+def _flat(s, frac=0.3, seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    sc = s.scales.clone()
+    pick = torch.rand(sc.shape[0], generator=gen) < frac
+    axis = torch.randint(0, 3, (sc.shape[0],), generator=gen)
+    sc[pick, axis[pick]] = 1e-6
+    return s._replace(scales=sc)
+
+
+def assert_forward_identical(r, o, s):
+    assert r.num_rendered == o.num_rendered
+    vis = r.get("radii") > 0
+    for n in INTS:
+        a, b = r.get(n), o.get(n)
+        if n == "clamped":     # written only for Gaussians that reach the colour stage (forward.cu:407-413); the rest is scratch
+            a, b = a.reshape(-1, 3)[vis], b.reshape(-1, 3)[vis]
+        assert a.shape == b.shape and np.array_equal(a, b), n
+    for n in GEOM + IMG:
+        a, b = r.get(n), o.get(n)
+        assert a.shape == b.shape, n
+        if n in GEOM:          # per-Gaussian arrays are defined for Gaussians that passed the near plane; compare the visible rows
+            k = a.size // vis.size
+            a, b = a.reshape(-1, k)[vis], b.reshape(-1, k)[vis]
+        assert np.array_equal(bits(a), bits(b)), n
+    for k, (a, b) in enumerate(zip(r.outputs(), o.outputs())):
+        assert np.array_equal(bits(a), bits(b)) if k != 1 else np.array_equal(a, b), f"output {k}"
+
+
+def assert_backward_identical(r, o, g):
+    r.backward(g["color"], g["coord"], g["mcoord"], g["depth"], g["mdepth"], g["alpha"], g["normal"])
+    go, gr = oracle_backward(o, g), r.grads()
+    for n in SUMS:
+        assert np.array_equal(bits(r.get(n)), bits(o.get(n))), n
+    for k in gr:
+        assert gr[k].shape == go[k].shape and np.array_equal(bits(gr[k]), bits(go[k])), k
+    return gr
+
+
+CASES = [
+    dict(P=10000, W=256, H=256, sh_degree=0, mu_px=1.5, seed=0, kernel_size=0.0, require_coord=False, require_depth=True),            # C1
+    dict(P=3000, W=200, H=120, sh_degree=3, mu_px=3.0, seed=1, kernel_size=0.1, require_coord=True, require_depth=True, pose="random"),
+    dict(P=3000, W=173, H=99, sh_degree=2, mu_px=4.0, seed=2, kernel_size=0.1, require_coord=True, require_depth=False, pose="random",
+         bg=(0.3, 0.1, 0.7)),                                                                                                          # ragged tiles
+    dict(P=3000, W=160, H=96, sh_degree=1, mu_px=3.0, seed=3, kernel_size=0.0, require_coord=False, require_depth=False, pose="random"),
+    dict(P=1500, W=96, H=80, sh_degree=3, mu_px=25.0, seed=4, kernel_size=0.1, require_coord=False, require_depth=True, pose="random"),  # overdraw:
+    dict(P=2500, W=128, H=96, sh_degree=3, mu_px=12.0, seed=5, kernel_size=0.0, require_coord=True, require_depth=True, low_opacity=True),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"P{c['P']}_{c['W']}x{c['H']}_c{int(c['require_coord'])}d{int(c['require_depth'])}_k{c['kernel_size']}")
+def test_forward_and_backward_bit_identical_to_the_compiled_reference(case):
+    s = make_scene(**case)
+    r, o = ref_for(s), oracle_for(s, nthreads=1)
+    r.forward(), o.forward()
+    assert r.num_rendered > case["P"]      # a real scene
+    assert_forward_identical(r, o, s)
+    gr = assert_backward_identical(r, o, upstream_grads(s, case["seed"]))
+    assert all(np.isfinite(v).all() for v in gr.values())
+    if case["mu_px"] >= 12:                # long lists: several 256-entry batches per tile, early termination exercised
+        ranges = r.get("ranges").reshape(-1, 2)
+        assert (ranges[:, 1] - ranges[:, 0]).max() > 256
+        ncon = r.get("n_contrib")[: s.H * s.W].reshape(s.H, s.W)
+        lens = (ranges[:, 1] - ranges[:, 0]).reshape((s.H + 15) // 16, (s.W + 15) // 16)
+        assert (ncon < np.kron(lens, np.ones((16, 16), int))[: s.H, : s.W]).any()
+
+
+def test_flat_gaussians_ill_conditioned_branch():
+    """lambda_min <= 1e-8: the outer-product inverse (forward.cu:150-154) and the eigenvector-perturbation backward
+    (backward.cu:336-350), plus the eigen-solver's early exits."""
+    s = _flat(make_scene(3000, 200, 120, sh_degree=2, mu_px=3.0, seed=11, kernel_size=0.1, require_coord=True, require_depth=True,
+                         pose="random"))
+    r, o = ref_for(s), oracle_for(s, nthreads=1)
+    r.forward(), o.forward()
+    assert_forward_identical(r, o, s)
+    assert_backward_identical(r, o, upstream_grads(s, 11))
+
+
+def test_precomputed_colours_covariance_and_scale_modifier():
+    s = make_scene(3000, 160, 120, sh_degree=0, mu_px=2.5, seed=5, kernel_size=0.1, require_coord=True, require_depth=True, pose="random")
+    cov, colors = cov3d_of(s), torch.rand(s.means3D.shape[0], 3, generator=torch.Generator().manual_seed(1))
+    for kw in (dict(colors=colors, cov3D=cov), dict(colors=colors), dict(cov3D=cov), dict(scale_modifier=1.7)):
+        r, o = ref_for(s, **kw), oracle_for(s, nthreads=1, **kw)
+        r.forward(), o.forward()
+        assert_forward_identical(r, o, s)
+        assert_backward_identical(r, o, upstream_grads(s, 5))
+
+
+def test_empty_and_fully_culled_scenes():
+    s = make_scene(64, 48, 32, sh_degree=1, seed=2, require_coord=True, require_depth=True, bg=(0.25, 0.5, 0.75))
+    m = s.means3D.clone()
+    m[:, 2] = -m[:, 2].abs() - 1.0
+    behind = s._replace(means3D=m)
+    r, o = ref_for(behind), oracle_for(behind, nthreads=1)
+    assert r.forward() == 0 and o.forward() == 0
+    for k, (a, b) in enumerate(zip(r.outputs(), o.outputs())):
+        assert np.array_equal(a, b), k
+    assert np.array_equal(r.outputs()[0], np.broadcast_to(np.float32([0.25, 0.5, 0.75])[:, None, None], (3, 32, 48)))
+    assert_backward_identical(r, o, upstream_grads(behind, 2))
+    assert not np.any(r.grads()["dL_dmeans3D"])
+    empty = s._replace(means3D=s.means3D[:0], opacities=s.opacities[:0], scales=s.scales[:0], rotations=s.rotations[:0], shs=s.shs[:0])
+    r = ref_for(empty)
+    assert r.forward() == 0 and not np.any(r.outputs()[0])   # P == 0: rasterize_points.cu:90 skips the call, outputs stay at their zero fill
+
+
+def test_mark_visible_and_msb_and_matrix_convention():
+    s = make_scene(5000, 64, 64, seed=3, pose="random", near_cull_frac=0.3)
+    assert np.array_equal(ref.mark_visible(s.means3D, s.viewmatrix, s.projmatrix), orc.mark_visible(s.means3D, s.viewmatrix, s.projmatrix))
+    for n in list(range(1, 70)) + [255, 256, 257, 7500, 8160, 8192, 32400, 65535, 65536, 1 << 20]:
+        assert ref.higher_msb(n) == orc.higher_msb(n), n
+    assert [ref.higher_msb(n) for n in (256, 8160, 7500, 8160, 32400)] == [9, 13, 13, 13, 15]
+    assert np.array_equal(ref.kat_mat3(), np.float32([12, 15, 18]))                                  # forward.cu:126-133
+    assert np.array_equal(orc.kat_mat3(), ref.kat_mat3())
+
+
+def test_eigen_solver_bit_identical():
+    """auxiliary.h:217-401 against oracle/oracle_eigen.h on covariance-like, degenerate, diagonal and tiny matrices."""
+    rng = np.random.default_rng(0)
+    mats = []
+    for _ in range(3000):
+        A = rng.normal(size=(3, 3)) * np.exp(rng.normal(size=(1, 3)) * 2)
+        S = A @ A.T * 10.0 ** rng.uniform(-6, 2)
+        mats.append([S[0, 0], S[0, 1], S[0, 2], S[1, 1], S[1, 2], S[2, 2]])
+    mats += [[1, 0, 0, 1, 0, 1], [2, 0, 0, 3, 0, 5], [1, 0, 0, 1e-12, 0, 1], [0, 0, 0, 0, 0, 0], [1, 1, 1, 1, 1, 1], [1e-9, 0, 0, 1e-9, 0, 1e-9],
+             [4, 1e-8, 0, 4, 1e-8, 4], [1, 0, 1e-7, 2, 0, 3]]
+    nz = 0
+    for m in mats:
+        Dr, er, Vr = ref.sym_eigen3(m)
+        Do, eo, Vo = orc.sym_eigen3(m)
+        assert Dr == Do
+        assert np.array_equal(bits(er), bits(eo)) and np.array_equal(bits(Vr), bits(Vo)), m
+        nz += Dr != 0
+    assert nz > 2900
+
+
+def test_integrate_bit_identical():
+    """GaussianRasterizer.integrate: forward.cu:187-235 (INTE branch), :855-900, :938-1372, rasterizer_impl.cu:573-843."""
+    for flat in (False, True):
+        s = make_scene(2500, 160, 112, sh_degree=2, mu_px=4.0, seed=21 + flat, kernel_size=0.0, pose="random", require_coord=False, require_depth=True)
+        if flat:
+            s = _flat(s, frac=0.4, seed=3)
+        rng = np.random.default_rng(5)
+        vis = (ref.mark_visible(s.means3D, s.viewmatrix, s.projmatrix)).nonzero()[0]
+        base = s.means3D.numpy()[rng.choice(vis, 6000)]
+        pts = (base + rng.normal(size=base.shape) * 0.05).astype(np.float32)
+        pts[:50] = s.means3D.numpy()[:50] * [1, 1, -1]                      # some behind the camera / outside the image
+        r, o = ref_for(s), oracle_for(s, nthreads=1)
+        outs_r, outs_o = r.integrate(pts), o.integrate(pts)
+        assert r.num_rendered == o.num_rendered
+        vg = r.get("radii") > 0
+        assert np.array_equal(r.get("condition")[: s.means3D.shape[0]][vg], o.get("condition")[vg])
+        assert np.array_equal(bits(r.get("invraycov").reshape(-1, 6)[vg]), bits(o.get("invraycov").reshape(-1, 6)[vg]))
+        names = ["out9", "alpha_integrated", "color_integrated", "coordinate2d", "sdf", "radii"]
+        for n, a, b in zip(names, outs_r, outs_o):
+            assert a.shape == b.shape, n
+            assert np.array_equal(a, b) if n == "radii" else np.array_equal(bits(a), bits(b)), n
+        assert (outs_r[1] < 1.0).sum() > 1000 and (outs_r[0][8] > 0).sum() > 500   # points were integrated, pixels hold several points
+
+
+def test_fma_contraction_sensitivity():
+    """What nvcc's default mul+add contraction can move.  The reference's sources rebuilt with
+    -ffp-contract=fast -mfma (gcc picks the pairs, so this is a probe of the sensitivity, not a CUDA emulation) against the
+    contraction-free build, both with the specified exponential: how many radii / tile counts / instances / contributor counts
+    change, and how far the maps move.  DESIGN.md section 7 quotes the printed numbers."""
+    ref.set_exp("spec", fma=True)
+    ref.set_num_threads(1, fma=True)
+    report = {}
+    for name, kw in (("C1", dict(P=10000, W=256, H=256, sh_degree=0, mu_px=1.5, seed=0, require_coord=False, require_depth=True)),
+                     ("C2-shaped 100k @ 608x342", dict(P=100000, W=608, H=342, sh_degree=3, mu_px=1.5, seed=1, require_coord=False, require_depth=True))):
+        s = make_scene(**kw)
+        a, b = ref_for(s), ref_for(s, fma=True)
+        ref.set_num_threads(8), ref.set_num_threads(8, fma=True)
+        Ra, Rb = a.forward(), b.forward()
+        ref.set_num_threads(1), ref.set_num_threads(1, fma=True)
+        P, N = s.means3D.shape[0], s.H * s.W
+        d_radii = int((a.get("radii") != b.get("radii")).sum())
+        d_tiles = int((a.get("tiles_touched") != b.get("tiles_touched")).sum())
+        d_key = int((bits(a.get("depths")) != bits(b.get("depths")))[a.get("radii") > 0].sum())
+        nca, ncb = a.get("n_contrib"), b.get("n_contrib")
+        d_last, d_med = int((nca[:N] != ncb[:N]).sum()), int((nca[N:] != ncb[N:]).sum())
+        oa, ob = a.outputs(), b.outputs()
+        same = (nca[:N] == ncb[:N]).reshape(s.H, s.W)
+        dmax = {k: float(np.abs(oa[i].astype(np.float64) - ob[i])[..., same].max()) for k, i in (("color", 0), ("depth", 4), ("alpha", 6), ("normal", 7))}
+        report[name] = dict(P=P, radii_changed=d_radii, tiles_touched_changed=d_tiles, num_rendered=(Ra, Rb), depth_key_bits_changed=d_key,
+                            n_contrib_last_changed=d_last, n_contrib_median_changed=d_med, pixels=N, max_map_diff_where_same_decisions=dmax)
+        # contraction moves low-order bits of the projected covariance: a handful of radii/tile rects at most, no visible image change
+        assert d_radii <= max(3, P // 2000) and d_tiles <= max(3, P // 2000), report
+        assert abs(Ra - Rb) <= max(8, Ra // 5000), report
+        assert d_last <= N // 200, report
+        assert dmax["color"] < 5e-5 and dmax["alpha"] < 5e-5, report
+    print("fma contraction sensitivity:", report)
+    ref.set_exp("libm", fma=True)
