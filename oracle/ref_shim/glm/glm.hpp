@@ -15,7 +15,7 @@
 // One difference from GLM: a default-constructed mat3 is ZERO here (GLM leaves it uninitialised).  The only place the reference reads
 // such a matrix is the shadowed `inv_cov_ray` of the ill-conditioned INTE branch (forward.cu:196 vs :223), i.e. undefined upstream.
 // The reference's own known-answer comment (forward.cu:126-133: mat3(1..9)*(1,1,1) = (12,15,18)) is checked against this header
-// by tests/test_ref_build.py.
+// by tests/test_ref_parity.py::test_mark_visible_and_msb_and_matrix_convention.
 #pragma once
 #include <cmath>
 

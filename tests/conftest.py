@@ -11,6 +11,39 @@ for p in (ROOT, os.path.join(ROOT, "rade-gs_amd"), os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "executed_grad: run with the backward the reference EXECUTES (its argument slip included), "
+                                       "the product's and the oracle's default, instead of the intended derivative")
+
+
+@pytest.fixture(autouse=True)
+def _gradient_mode(request):
+    """Which backward the gradient comparisons run against.
+
+    The reference hands `dL_dconic` to BACKWARD::preprocess where that function expects `conic_opacity` (rasterizer_impl.cu:568;
+    found by running the reference's own sources on the host, oracle/_ref), so the backward it EXECUTES scales the opacity-
+    compensation term by an accumulated gradient sum (|dL_dconic.w| reaches 1e3..1e4) instead of an opacity <= 1.  Product and
+    oracle reproduce that by default (include/radegs.h::opacity_grad_intended, oracle.set_opacity_slip).  At the reference's default
+    kernel_size = 0 the extra term is a cancellation residue: it makes the reference's own geometry gradients move by 1e-4..1e-3 of
+    their scale when its float atomics land in a different order (300x the sensitivity of the intended derivative), so no fp32
+    implementation can match it elementwise at 1e-5 / 1e-4.  The strict fp32 criteria of the gradient tests therefore run on the
+    INTENDED derivative -- everything but one operand select is shared between the two modes -- and the executed mode is pinned
+    separately: bit for bit oracle == compiled reference (tests/test_ref_parity.py), golden vectors (tests/test_golden.py) and the
+    HIP path against both with the reference's own order noise as the band (tests/test_gpu_executed_grad.py).  Tests marked
+    `executed_grad` keep the defaults."""
+    from oracle import oracle as orc
+    executed = request.node.get_closest_marker("executed_grad") is not None
+    try:
+        import diff_gaussian_rasterization._C as C
+    except Exception:       # product library absent (a CPU-only checkout before build()): oracle-only tests still run
+        C = None
+    prev = None if C is None else C.OPACITY_GRAD_INTENDED
+    orc.set_opacity_slip(1 if executed else 0)
+    if C is not None:
+        C.OPACITY_GRAD_INTENDED = not executed
+    yield
+    orc.set_opacity_slip(1)
+    if C is not None:
+        C.OPACITY_GRAD_INTENDED = prev
 
 
 @pytest.fixture(scope="session", autouse=True)

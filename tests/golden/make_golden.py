@@ -58,6 +58,14 @@ def run_reference(case):
     r.backward(g["color"], g["coord"], g["mcoord"], g["depth"], g["mdepth"], g["alpha"], g["normal"])
     d = _pack(R, out, r.get, r.grads())
     ref.set_exp("libm")
+    # the reference's own order noise: the same backward with the per-Gaussian sums formed in another order (double accumulators)
+    from oracle import oracle as orc
+    orc.set_opacity_slip(1)
+    o = oracle_for(s, nthreads=1)
+    o.forward()
+    other = oracle_backward(o, g)
+    for k, v in r.grads().items():
+        d["noise_" + k] = np.float64(np.abs(v.astype(np.float64) - other[k]).max()) if v.size else np.float64(0)
     fl = grad_noise_floor(s, g)      # None: the float64 run takes a different thresholded decision somewhere (larger scenes)
     for k in r.grads():
         d["floor_" + k] = np.float64(fl[0][k]) if fl is not None else np.float64("nan")

@@ -13,12 +13,13 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 import make_golden  # noqa: E402
 
 
+@pytest.mark.executed_grad
 @pytest.mark.parametrize("case", list(make_golden.CASES))
 def test_oracle_reproduces_golden(case):
     want = np.load(os.path.join(HERE, "golden", case + ".npz"))
     got = make_golden.run(case)
     for k in want.files:
-        if k.startswith("floor_"):
+        if k.startswith("floor_") or k.startswith("noise_"):
             continue
         a, b = np.asarray(got[k]), want[k]
         # -ffp-contract=off + IEEE ops + the specified exp on both sides: identical bits (NaN-safe comparison of the raw words)
@@ -27,6 +28,7 @@ def test_oracle_reproduces_golden(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.executed_grad
 @pytest.mark.parametrize("case", list(make_golden.CASES))
 def test_hip_matches_golden(case):
     import torch
@@ -56,5 +58,7 @@ def test_hip_matches_golden(case):
         scale = float(np.abs(b).max()) + 1e-30
         floor = float(want["floor_" + k])            # see util.grad_noise_floor; NaN: no float64 twin for this scene (DESIGN.md section 7:
         floor = 4e-5 * scale if floor != floor else floor   # |oracle32 - oracle64| is ~4e-5 of each tensor's scale)
-        band = ATOL + max(2e-6 * scale, 0.25 * floor)
+        # `noise_*`: how far the REFERENCE's own result moves when its float atomics are applied in another order (executed mode:
+        # the slip term is a cancellation residue, conftest._gradient_mode) -- no implementation can be closer to it than that
+        band = ATOL + max(2e-6 * scale, 0.25 * floor) + 4.0 * float(want["noise_" + k])
         assert close(got[k], b, atol=band, rtol=1e-3).all(), k

@@ -18,19 +18,7 @@ from synth_scene import make_scene, upstream_grads
 from torch_restatement import abs_grad_sum, render
 from util import cov3d_of, oracle_backward, oracle_for
 
-@pytest.fixture(autouse=True)
-def _intended_derivative():
-    """These tests check CALCULUS: the hand-derived backward against the derivative of the forward.  The reference as executed
-    deviates from its own formulas in one place -- the argument slip of rasterizer_impl.cu:568 (radegs_oracle.cpp::g_opacity_slip,
-    found with oracle/_ref) -- so the oracle is switched to the intended derivative here; tests/test_ref_parity.py pins the
-    executed behaviour (the default everywhere else) to the compiled reference."""
-    from oracle import oracle as orc
-    orc.set_opacity_slip(0)
-    yield
-    orc.set_opacity_slip(1)
-
-
-
+# (the conftest fixture `_gradient_mode` runs these calculus checks on the INTENDED derivative: oracle.set_opacity_slip(0))
 MODES = [(False, False), (False, True), (True, False), (True, True)]
 
 

@@ -23,7 +23,8 @@ from oracle import ref
 from synth_scene import make_scene, upstream_grads
 from util import cov3d_of, oracle_backward, oracle_for
 
-pytestmark = pytest.mark.skipif(not ref.available(), reason="reference sources (/root/reference) and prebuilt oracle/_ref both absent")
+pytestmark = [pytest.mark.skipif(not ref.available(), reason="reference sources (/root/reference) and prebuilt oracle/_ref both absent"),
+              pytest.mark.executed_grad]
 
 GEOM = ["depths", "camera_planes", "ray_planes", "ts", "normals", "means2D", "view_points", "cov3D", "conic_opacity", "rgb"]
 INTS = ["radii", "tiles_touched", "point_offsets", "clamped", "keys_sorted", "point_list", "ranges", "n_contrib"]
