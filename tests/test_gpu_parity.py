@@ -260,6 +260,18 @@ def test_tile_wide_backward_after_stream_forward(monkeypatch):
     check_backward(s, o, seed=64)
 
 
+@pytest.mark.parametrize("depth", [True, False])
+def test_half_row_stream_backward(monkeypatch, depth):
+    """blend_bwd_streams8_kernel (8 lanes x 4 pixels per block, the two half rows of a DPP row trade one sum so that every
+    (block, entry) still leaves as one full-line atomic): an alternative to the default 16-lane walk, same results."""
+    monkeypatch.setenv("RADEGS_STREAMS", "1")
+    monkeypatch.setenv("RADEGS_STREAMS_BWD8", "1")
+    s = make_scene(6000, 232, 168, sh_degree=2, mu_px=2.5, seed=65, kernel_size=0.1, require_coord=False, require_depth=depth, pose="random",
+                   bg=(0.1, 0.4, 0.7))
+    o, _ = check_forward(s)
+    check_backward(s, o, seed=65)
+
+
 def test_forward_is_deterministic_and_backward_stable():
     from gpu_util import HipRun
     s = make_scene(20000, 320, 240, sh_degree=3, mu_px=2.0, seed=8, require_coord=False, require_depth=True)
