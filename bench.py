@@ -37,6 +37,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# VALU issue peak in wave64 instructions: 256 CUs x 4 SIMDs x 2.4 GHz, one instruction every 2 cycles per SIMD (same guide: "issues each
+# VALU instruction over 2 cycles"; 157.3 TFLOP/s fp32 = this x 64 lanes x 2 flop)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
 
 
 def algorithmic_bytes(P, Pv, R, N, D, c, d):
@@ -57,6 +60,14 @@ def algorithmic_bytes(P, Pv, R, N, D, c, d):
     return st
 
 
+def binning_bytes_moved(P, R, tiles, streams):
+    """What THIS implementation's binning moves, as opposed to the reference algorithm's 16 P + 164 R that
+    `algorithmic_bytes` charges: depth sort of P 32-bit keys, 4 passes x (histogram reads the key, scatter reads key (+ value after
+    the first pass) and writes both) = 76 P; gather-scan 20 P; emission reads 12 P (index, offset, packed rectangle) + the 64-B record
+    of every visible splat when block masks are computed, writes 8 R; tile sort 2 passes x 20 R; ranges 4 R + 8 tiles."""
+    return 76 * P + 20 * P + 12 * P + 8 * R + 40 * R + 4 * R + 8 * tiles + (64 * P if streams else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +77,9 @@ def main():
     ap.add_argument("--points", type=int, default=0, help="override the number of Gaussians (debug only)")
     ap.add_argument("--mu-px", type=float, default=0.0, help="override the median splat size in pixels (debug only)")
     ap.add_argument("--views", type=int, default=9, help="distinct camera views the steps rotate through (1 = the same view every step)")
+    ap.add_argument("--flags", choices=("config", "both"), default="config",
+                    help="'both': require_coord = require_depth = True whatever the config says -- the render.py mode "
+                         "(gaussian_renderer/__init__.py:19,71-79: render() defaults), SURVEY.md 8(d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-allreduce", action="store_true", help="run the RCCL gradient exchange even at world size 1 (path check)")
     ap.add_argument("--exchange", choices=("factored", "allreduce"), default="factored",
@@ -98,6 +112,8 @@ def main():
     if args.mu_px:
         over["mu_px"] = args.mu_px
     cfg = dict(CONFIGS[args.config])
+    if args.flags == "both":
+        over["require_coord"] = over["require_depth"] = True
     scene_cpu = make_config(args.config, **over)
     # the view stream of this rank: view 0 of rank 0 is the config's own view; the last one is the dolly-in view
     nviews = max(1, args.views)
@@ -121,6 +137,7 @@ def main():
             bucket = GradBucket(P, s.shs.shape[1], dev)
         C.set_grad_allocator(dev, bucket.allocator)
     counter = [0]
+    last_state = []
 
     def step():
         vm, pm, cp = cams[counter[0] % nviews]
@@ -134,6 +151,7 @@ def main():
                                             g["mdepth"], g["alpha"], g["normal"], normal, s.shs, s.sh_degree, cp, geom, R,
                                             binning, img, alpha, s.require_coord, s.require_depth, False)
         grads = dict(dL_dmeans3D=bw[3], dL_dsh=bw[5], dL_dopacity=bw[2], dL_dscales=bw[6], dL_drotations=bw[7])
+        last_state[:] = [R, geom, binning, img]
         if bucket is not None:  # the one exchange step of the path (RCCL over xGMI)
             grads = bucket.exchange(s.means3D, cp, average=True) if args.exchange == "factored" else bucket.allreduce(average=True)
         return R, radii, grads
@@ -205,9 +223,15 @@ def main():
         achieved = ab[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         gpu_ms = sum(grouped.values())
         kernel_name = {"blend_bwd": "blend_bwd_"}.get(dom, dom + "_")   # prefix of the kernel's name in the rocprof summaries
-        traffic, traffic_note = pmc_traffic(kernel_name, args.config, P, W, H)
+        tag = args.config if args.flags == "config" else args.config + "_both"
+        traffic, traffic_note = pmc_traffic(kernel_name, tag, args.config, P, W, H)
+        pairs = pair_evaluations(C, s, last_state, c)
+        streams = pairs["formulation"].startswith("entry streams")
+        bmoved = binning_bytes_moved(P, R, ((W + 15) // 16) * ((H + 15) // 16), streams)
+        valu = valu_roofline(kernel_name, tag, args.config, P, W, H, dom_ms)
         out = {
-            "metric": "fwd+bwd Msplats/s @1080p, 1M Gaussians; depth L1 vs ref" if args.config == "C2" else f"fwd+bwd Msplats/s, {args.config}", "value": round(value, 2), "unit": "Msplats/s",
+            "metric": ("fwd+bwd Msplats/s @1080p, 1M Gaussians; depth L1 vs ref" if args.config == "C2" else f"fwd+bwd Msplats/s, {args.config}")
+                      + (" [render.py mode: coord + depth maps]" if args.flags == "both" else ""), "value": round(value, 2), "unit": "Msplats/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH degree {s.sh_degree}, fwd+bwd one view per step per GPU, "
@@ -229,6 +253,16 @@ def main():
             "stages_ms": {k: round(v, 4) for k, v in ms.items()},
             "stages_ms_source": "warm-up steps with an event pair per stage; the roofline kernel is re-timed alone inside the timed steps",
             "stage_GBs": {k: round(ab[k] / (grouped[k] * 1e-3) / 1e9, 1) if grouped[k] > 0 else 0.0 for k in grouped},
+            # the binning line above divides the REFERENCE algorithm's bytes (6-pass 64-bit sort) by this implementation's time; what the
+            # implementation itself moves is about half of that (binning_bytes_moved)
+            "binning_bytes_moved": {"bytes": int(bmoved), "GBs": round(bmoved / (grouped["binning"] * 1e-3) / 1e9, 1) if grouped["binning"] > 0 else 0.0},
+            # the render kernels are gather + ALU bound -- (pixel, list entry) evaluations per second next to their GB/s
+            "pairs": {"formulation": pairs["formulation"], "evaluated_per_pass": pairs["evaluated"], "reference_definition_per_pass": pairs["tilewide"],
+                      "blend_fwd_Gpairs_s": round(pairs["evaluated"] / (ms["blend_fwd"] * 1e-3) / 1e9, 1) if ms["blend_fwd"] > 0 else 0.0,
+                      "blend_bwd_Gpairs_s": round(pairs["evaluated"] / (ms["blend_bwd"] * 1e-3) / 1e9, 1) if ms["blend_bwd"] > 0 else 0.0,
+                      "note": "evaluated = pixel slots the kernels walk in the last view of the run (entry streams: 32 x entries each 8x4 block "
+                              "consumed); reference_definition = 256 x entries each tile's walk reaches (SURVEY 8d)"},
+            "valu_roofline": valu,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_cpu, cfg["seed"])
@@ -238,20 +272,66 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel_name, config, P, W, H):
-    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/*_pmc_per_kernel.json:
-    separate `rocprofv3 --pmc` runs of this same command, TCC_EA0_RDREQ/WRREQ x 64 B as MI355X_MICROARCH.md's HBM section
-    prescribes; its gfx950 note applies: 16-B/lane streaming reads may be under-counted up to 2x).  Counters cannot be
-    collected inside a timed run, so the value is only reported for the workload the pass was made on; else null."""
+def pair_evaluations(C, s, last_state, coord):
+    """(pixel, list entry) evaluations of one blend pass over the last view rendered, from the state the forward left."""
+    import numpy as np
+    R, geom, binning, img = last_state
+    W, H, P = s.W, s.H, s.means3D.shape[0]
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    if R == 0:
+        return {"formulation": "empty", "evaluated": 0, "tilewide": 0}
+    ncon = C.debug_export("n_contrib", torch.int32, 2 * W * H, P, R, W, H, coord, geom, binning, img)[: W * H].view(H, W)
+    pad = torch.zeros(((H + 15) // 16) * 16, ((W + 15) // 16) * 16, dtype=torch.int32, device=ncon.device)
+    pad[:H, :W] = ncon
+    reach = pad.view(pad.shape[0] // 16, 16, pad.shape[1] // 16, 16).amax(dim=(1, 3)).to(torch.int64)   # per tile: last entry any pixel blended
+    tilewide = int(256 * reach.sum().item())
+    env = os.environ.get("RADEGS_STREAMS")
+    streams = (not coord) and (R < 24 * P if env is None else env != "0")
+    if streams:
+        cons = C.debug_export("blk_consumed", torch.int32, 8 * tiles, P, R, W, H, coord, geom, binning, img).to(torch.int64)
+        return {"formulation": "entry streams (8x4-pixel blocks)", "evaluated": int(32 * cons.sum().item()), "tilewide": tilewide}
+    return {"formulation": "tile-wide lists", "evaluated": tilewide, "tilewide": tilewide}
+
+
+def _pmc_file(tag, config, P, W, H):
     import glob
     from synth_scene import CONFIGS
     c = CONFIGS.get(config)
     if c is None or (P, W, H) != (c["P"], c["W"], c["H"]):
+        return None
+    suffix = "" if tag == "C2" else "_" + tag
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r[0-9][0-9]{suffix}_pmc_per_kernel.json")))
+    return files[-1] if files else None
+
+
+def valu_roofline(kernel_name, tag, config, P, W, H, dom_ms):
+    """The bound the blend kernels actually run into: wave64 VALU instructions per launch from the committed
+    PMC pass (SQ_INSTS_VALU) / the live launch duration, against the issue peak of the chip."""
+    f = _pmc_file(tag, config, P, W, H)
+    if f is None or dom_ms <= 0:
+        return None
+    try:
+        for name, v in json.load(open(f)).items():
+            if kernel_name in name and "SQ_INSTS_VALU" in v:
+                ach = v["SQ_INSTS_VALU"] / (dom_ms * 1e-3) / 1e9
+                return {"bound": "valu", "kernel": kernel_name, "achieved": round(ach, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instructions/s",
+                        "frac": round(ach / VALU_PEAK_GINST, 4), "wave_instructions_per_launch": int(v["SQ_INSTS_VALU"]),
+                        "source": os.path.basename(f) + ": SQ_INSTS_VALU per launch (separate --pmc pass); peak = 1024 SIMDs x 2.4 GHz / 2 cycles per "
+                                  "instruction -- half-rate classes (DPP, select, compare: DESIGN 4.3) make 1.0 unreachable"}
+    except Exception:
+        return None
+    return None
+
+
+def pmc_traffic(kernel_name, tag, config, P, W, H):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/*_pmc_per_kernel.json:
+    separate `rocprofv3 --pmc` runs of this same command, TCC_EA0_RDREQ/WRREQ x 64 B as MI355X_MICROARCH.md's HBM section
+    prescribes; its gfx950 note applies: 16-B/lane streaming reads may be under-counted up to 2x).  Counters cannot be
+    collected inside a timed run, so the value is only reported for the workload the pass was made on; else null."""
+    f = _pmc_file(tag, config, P, W, H)
+    if f is None:
         return None, "no PMC pass for this workload"
-    tag = "" if config == "C2" else "_" + config
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r[0-9][0-9]{tag}_pmc_per_kernel.json")))
-    if not files:
-        return None, f"profiles/rNN{tag}_pmc_per_kernel.json not found"
+    files = [f]
     try:
         d = json.load(open(files[-1]))
         for name, v in d.items():
@@ -280,9 +360,45 @@ def cpu_baseline(scene_cpu, seed):
     o.backward(g["color"], g["coord"], g["mcoord"], g["depth"], g["mdepth"], g["alpha"], g["normal"])
     t2 = time.perf_counter()
     P = s.means3D.shape[0]
-    return {"value": round(P / 1e6 / (t2 - t0), 4), "unit": "Msplats/s", "cores": cores, "kind": "port",
+    port = {"value": round(P / 1e6 / (t2 - t0), 4), "unit": "Msplats/s", "cores": cores, "kind": "port",
             "sample": f"1 fwd+bwd pass over the full workload view ({P} Gaussians, {s.W}x{s.H}); fwd {t1 - t0:.2f} s, bwd {t2 - t1:.2f} s, "
                       f"OpenMP over Gaussians/tiles"}
+    o.close()
+    ref = cpu_baseline_reference(s, g, cores)
+    if ref is None:
+        return port
+    ref["port"] = {k: port[k] for k in ("value", "sample")}
+    return ref
+
+
+def cpu_baseline_reference(s, g, cores):
+    """kind "reference": the reference's OWN rasterizer sources (forward.cu / backward.cu / rasterizer_impl.cu) compiled for the host
+    (oracle/_ref, built by oracle/build_ref.py where /root/reference exists; the .so travels to the GPU box) and driven through
+    CudaRasterizer::Rasterizer::forward / backward: thread blocks as fibers, blocks spread over the host cores with OpenMP.  None when
+    the library is not there."""
+    try:
+        from oracle import ref
+        if not os.path.exists(ref.lib_path()):
+            return None
+        ref.set_exp("libm")
+        ref.set_num_threads(cores)
+        r = ref.Ref(bg=s.bg, means3D=s.means3D, opacities=s.opacities, viewmatrix=s.viewmatrix, projmatrix=s.projmatrix, campos=s.campos,
+                    tanfovx=s.tanfovx, tanfovy=s.tanfovy, image_height=s.H, image_width=s.W, shs=s.shs, scales=s.scales,
+                    rotations=s.rotations, sh_degree=s.sh_degree, kernel_size=s.kernel_size, require_coord=s.require_coord,
+                    require_depth=s.require_depth)
+        t0 = time.perf_counter()
+        r.forward()
+        t1 = time.perf_counter()
+        r.backward(g["color"], g["coord"], g["mcoord"], g["depth"], g["mdepth"], g["alpha"], g["normal"])
+        t2 = time.perf_counter()
+        ref.set_num_threads(1)
+        P = s.means3D.shape[0]
+        return {"value": round(P / 1e6 / (t2 - t0), 4), "unit": "Msplats/s", "cores": cores, "kind": "reference",
+                "sample": f"1 fwd+bwd pass over the full workload view ({P} Gaussians, {s.W}x{s.H}) through the reference's own sources compiled "
+                          f"for the host (CUDA blocks as fibers, OpenMP over blocks); fwd {t1 - t0:.2f} s, bwd {t2 - t1:.2f} s"}
+    except Exception as ex:   # the bench line must not die on the optional leg
+        sys.stderr.write(f"[bench] reference cpu_baseline skipped: {ex}\n")
+        return None
 
 
 if __name__ == "__main__":

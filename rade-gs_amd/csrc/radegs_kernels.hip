@@ -67,6 +67,7 @@ struct PreFwdArgs {
   int* radii; float4* splat_a; float4* splat_b; uint32_t* tiles_touched; uint32_t* depth_key; uint8_t* clamped;
   float4* inte_rec;  // [P][2] {icr0..icr3 | icr4, icr5, well, 0}; INTE kernel only
   uint32_t* rect;    // [P] packed tile rectangle
+  float4* eig;       // [P][3] the solver's eigenvalues / eigenvectors, for the backward
 };
 
 template <bool INTE>
@@ -97,7 +98,13 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(const PreFwdArgs a)
       rb[1] = make_float4(s.cp[4], s.cp[5], s.vp[0], s.vp[1]);
       rb[2] = make_float4(s.vp[2], 0.f, 0.f, 0.f);
     }
-    a.clamped[idx] = (uint8_t)s.clamped;
+    a.clamped[idx] = (uint8_t)(s.clamped | (s.eigD != 0 ? 8u : 0u));   // bits 0..2: SH clamp flags; bit 3: eigen-solver converged
+    {
+      float4* re = a.eig + 3 * (size_t)idx;
+      re[0] = make_float4(s.eig[0], s.eig[1], s.eig[2], s.eig[3]);
+      re[1] = make_float4(s.eig[4], s.eig[5], s.eig[6], s.eig[7]);
+      re[2] = make_float4(s.eig[8], s.eig[9], s.eig[10], s.eig[11]);
+    }
     if constexpr (INTE) {
       float4* ri = a.inte_rec + 2 * (size_t)idx;
       ri[0] = make_float4(s.icr[0], s.icr[1], s.icr[2], s.icr[3]);
@@ -994,18 +1001,27 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 2 : (PPL == 2 ? 3 : 5
           // alpha.  The DECISION alpha < 1/255 must be the forward's (exp_spec); the VALUE may come from
           // the hardware exp (3e-7 relative): only when op*exp is within 1e-4 of the threshold is the
           // specified exponential evaluated, so the decision is always the exact one.
+#if defined(RADEGS_BWD_EXACT)   // analysis build (scripts/gpu_fuzz_table.py): the oracle's arithmetic for alpha and T
+          float G = exp_spec(power[s]);
+          float a_raw = B.y * G;
+#else
           float G = __expf(power[s]);
           float a_raw = B.y * G;
           if (fabsf(fmaf(a_raw, 255.0f, -1.0f)) < 1.0e-4f) {
             G = exp_spec(power[s]);
             a_raw = B.y * G;
           }
+#endif
           const float alpha = fminf(0.99f, a_raw);
           if (!(alpha < 1.0f / 255.0f)) {
             contributed = true;
             const float dy = A.y - pixfy[s];
             const float one_m_a = 1.f - alpha;
+#if defined(RADEGS_BWD_EXACT)
+            const float inv1ma = 1.0f / one_m_a;
+#else
             const float inv1ma = rcp_refined(one_m_a);  // no decision depends on T here; the refinement keeps the T chain at division accuracy
+#endif
             T[s] = T[s] * inv1ma;
             const float dch = alpha * T[s];
             float dL_dopa = 0.f;
@@ -1290,7 +1306,11 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
       for (int q = 0; q < NP; q++) {
         if (!__any(cand[2 * q] || cand[2 * q + 1])) continue;  // wave-uniform
         // ---- alpha (decision = forward's exp_spec rule; value from the hardware exp) ----
+#if defined(RADEGS_BWD_EXACT)   // analysis build (scripts/gpu_fuzz_table.py): the oracle's arithmetic for alpha and T
+        f2 G = f2{exp_spec(power[q][0]), exp_spec(power[q][1])};
+#else
         f2 G = f2{__expf(power[q][0]), __expf(power[q][1])};
+#endif
         f2 a_raw = bc2(B.y) * G;
         {
           const bool b0 = fabsf(fmaf(a_raw[0], 255.0f, -1.0f)) < 1.0e-4f, b1 = fabsf(fmaf(a_raw[1], 255.0f, -1.0f)) < 1.0e-4f;
@@ -1305,7 +1325,11 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
         alpha = f2{act0 ? alpha[0] : 0.f, act1 ? alpha[1] : 0.f};
         G = f2{act0 ? G[0] : 0.f, act1 ? G[1] : 0.f};
         const f2 one_m_a = bc2(1.f) - alpha;
+#if defined(RADEGS_BWD_EXACT)
+        const f2 inv1ma = f2{1.0f / one_m_a[0], 1.0f / one_m_a[1]};
+#else
         const f2 inv1ma = f2{rcp_refined(one_m_a[0]), rcp_refined(one_m_a[1])};
+#endif
         T[q] = T[q] * inv1ma;
         const f2 dch = alpha * T[q];
         // V = <cotangent of this pixel, blended quantities of this Gaussian>; dL/dalpha's blend part = V - Q
@@ -1407,6 +1431,7 @@ struct PreBwdArgs {
   int P, D, M;
   const float* means3D; const float* scales; const float* rotations; const float* cov3D_precomp; const float* shs;
   const int* radii; const float4* splat_a; const uint8_t* clamped; const float* acc; int rec;
+  const float4* eig;   // [P][3] the forward's eigen-decomposition (GeomState::eig), or null: re-run the solver
   CamArgs cam;
   float* dL_dmean2D; float* dL_dcolor; float* dL_dopacity; float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale;
   float* dL_drot;
@@ -1514,8 +1539,16 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
       }
       SplatBwd o;
       o.dscale[0] = o.dscale[1] = o.dscale[2] = 0; o.drot[0] = o.drot[1] = o.drot[2] = o.drot[3] = 0;
+      const unsigned cflags = (unsigned)a.clamped[idx];   // bits 0..2: SH clamp flags; bit 3: the forward's eigen-solver converged
+      float eigc[12];
+      if (a.eig) {
+        const float4* re = a.eig + 3 * i;
+        const float4 e0 = re[0], e1 = re[1], e2 = re[2];
+        eigc[0] = e0.x; eigc[1] = e0.y; eigc[2] = e0.z; eigc[3] = e0.w; eigc[4] = e1.x; eigc[5] = e1.y; eigc[6] = e1.z; eigc[7] = e1.w;
+        eigc[8] = e2.x; eigc[9] = e2.y; eigc[10] = e2.z; eigc[11] = e2.w;
+      }
       preprocess_bwd(mk3(m[0], m[1], m[2]), has_sr ? sc3 : nullptr, has_sr ? rq4 : nullptr, cov, op_combined, a.D, row,
-                     (unsigned)a.clamped[idx], cam, acc, row, o);
+                     cflags & 7u, cam, acc, row, o, a.eig ? eigc : nullptr, (cflags & 8u) ? 3 : 0);
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         a.dL_dmean2D[3 * i + c] = acc.dmean2D[c];
@@ -1525,7 +1558,7 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
       }
       a.dL_dopacity[i] = o.dopacity;
       if (a.dL_drgb_clamped) {
-        const unsigned cl = (unsigned)a.clamped[idx];
+        const unsigned cl = (unsigned)a.clamped[idx] & 7u;
 #pragma unroll
         for (int c = 0; c < 3; c++) a.dL_drgb_clamped[3 * i + c] = acc.dcolor[c] * (((cl >> c) & 1u) ? 0.f : 1.f);
       }

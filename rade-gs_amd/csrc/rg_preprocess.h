@@ -82,7 +82,9 @@ struct Cov2D {
   v3 uvh, uvh_m, uvh_mn;
 };
 
-RG_HD void cov2d_common(v3 mean, const Camera& cam, const float cov3D[6], Cov2D& o) {
+// cached != nullptr: the forward's eigen-decomposition of this covariance ({d0,d1,d2, a0..a8}) and the solver's status; the
+// iterative solver is deterministic, so reusing its output gives the same bits as re-running it
+RG_HD void cov2d_common(v3 mean, const Camera& cam, const float cov3D[6], Cov2D& o, const float* cached = nullptr, int cached_D = 0) {
   v3 t = xform43(mean, cam.view);
   const float limx = 1.3f * cam.tan_fovx, limy = 1.3f * cam.tan_fovy;
   float txtz = t.x / t.z, tytz = t.y / t.z;
@@ -106,7 +108,15 @@ RG_HD void cov2d_common(v3 mean, const Camera& cam, const float cov3D[6], Cov2D&
   o.det1 = (float)fmax(1e-6, (double)((c00 + ks) * (c11 + ks) - c01 * c01));
   o.coef = (float)sqrt((double)o.det0 / ((double)o.det1 + 1e-6) + 1e-6);
 
-  o.D = sym_eigen3(o.Vrk.c[0][0], o.Vrk.c[1][0], o.Vrk.c[2][0], o.Vrk.c[1][1], o.Vrk.c[2][1], o.Vrk.c[2][2], o.eig);
+  if (cached) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) o.eig.d[i] = cached[i];
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.eig.a[i] = cached[3 + i];
+    o.D = cached_D;
+  } else {
+    o.D = sym_eigen3(o.Vrk.c[0][0], o.Vrk.c[1][0], o.Vrk.c[2][0], o.Vrk.c[1][1], o.Vrk.c[2][1], o.Vrk.c[2][2], o.eig);
+  }
   const float e0 = o.eig.d[0], e1 = o.eig.d[1], e2 = o.eig.d[2];
   o.min_id = e0 > e1 ? (e1 > e2 ? 2 : 1) : (e0 > e2 ? 2 : 0);
   const float emin = o.min_id == 0 ? e0 : (o.min_id == 1 ? e1 : e2);
@@ -145,6 +155,8 @@ struct SplatFwd {
   // 3D covariance was well conditioned (computeCov2D<true>, forward.cu:187-235)
   float icr[6];
   bool well;
+  float eig[12];        // {d0,d1,d2, a0..a8} of the solver (kept for the backward) and its status
+  int eigD;
 };
 
 // SH -> RGB (+0.5, clamp at 0, remember which channels clamped).  sh points at this
@@ -207,6 +219,11 @@ RG_HD void preprocess_fwd(v3 p_orig, const float* scale3, const float* quat4, co
 
   Cov2D g;
   cov2d_common(p_orig, cam, cov3D, g);
+#pragma unroll
+  for (int i = 0; i < 3; i++) o.eig[i] = g.eig.d[i];
+#pragma unroll
+  for (int i = 0; i < 9; i++) o.eig[3 + i] = g.eig.a[i];
+  o.eigD = g.D;
   const float ks = cam.kernel_size;
   const float cvx = g.cov.c[0][0] + ks, cvy = g.cov.c[0][1], cvz = g.cov.c[1][1] + ks;
   float coef = g.coef;

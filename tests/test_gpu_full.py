@@ -149,7 +149,7 @@ def test_full_size_oracle_parity(name):
     o = oracle_for(s)
     o.forward()
     _forward_checks(s, o)
-    _backward_checks(s, o, CONFIGS[name]["seed"])
+    _backward_checks(s, o, CONFIGS[name]["seed"], arbiter=True)   # the fp64 arbiter wherever a gradient is checked
 
 
 def test_C4_shape_coord_map_reduced():

@@ -57,7 +57,7 @@ def check_forward(s, colors=None, cov3D=None, scale_modifier=1.0):
 
 
 def check_backward(s, o, colors=None, cov3D=None, seed=0, ill_mask=None, min_strict=0.99, scale_modifier=1.0, rms_factor=1.1,
-                   max_factor=1.25, band_factor=1.0):
+                   max_factor=1.25, band_factor=1.0, collect=None):
     """ill_mask: rows (Gaussians) whose covariance is (nearly) singular.  Their per-Gaussian chain rule
     multiplies the accumulated sums by ~1/lambda_min (backward.cu:333-350), so the 1e-7 relative fp32
     reordering noise of the sums is amplified without bound; for those rows the check moves to where the
@@ -65,6 +65,13 @@ def check_backward(s, o, colors=None, cov3D=None, seed=0, ill_mask=None, min_str
     chain rule (which is bit-exact given identical sums: tests/test_hostcheck.py)."""
     import diff_gaussian_rasterization._C as C
     from gpu_util import HipRun
+
+    def chk(ok, name, criterion, measured, allowed, msg):   # collect is a list: record every failed criterion instead of raising
+        if ok:
+            return
+        if collect is None:
+            raise AssertionError(msg)
+        collect.append((name, criterion, float(measured), float(allowed)))
     g = upstream_grads(s, seed)
     ref = oracle_backward(o, g)
     h = HipRun(s, _dev(), colors=colors, cov3D=cov3D, scale_modifier=scale_modifier)
@@ -93,8 +100,9 @@ def check_backward(s, o, colors=None, cov3D=None, seed=0, ill_mask=None, min_str
     for c in range(rec if rec == 16 else 25):
         a, b = acc[vis, c], ref_acc[vis, c]
         scale = float(np.abs(b).max()) + 1e-30
-        assert close(a, b, atol=ATOL + 1e-4 * scale, rtol=1e-3).all(), f"acc[{c}] max abs diff {np.abs(a - b).max():.3e} (scale {scale:.3e})"
-        assert frac_close(a, b) > min_strict, f"acc[{c}]"
+        chk(close(a, b, atol=ATOL + 1e-4 * scale, rtol=1e-3).all(), f"acc[{c}]", "band", np.abs(a - b).max(), ATOL + 1e-4 * scale,
+            f"acc[{c}] max abs diff {np.abs(a - b).max():.3e} (scale {scale:.3e})")
+        chk(frac_close(a, b) > min_strict, f"acc[{c}]", "strict fraction", frac_close(a, b), min_strict, f"acc[{c}]")
     # ---- returned gradients ----
     # Criterion 1 (direct): >= 99 % of all elements inside the strict 1e-5 abs / 1e-4 rel bar vs the fp32
     # oracle, the rest inside a band set by the fp32 noise floor of the algorithm (util.grad_noise_floor).
@@ -114,13 +122,16 @@ def check_backward(s, o, colors=None, cov3D=None, seed=0, ill_mask=None, min_str
         scale = float(np.abs(b).max()) + 1e-30
         band = ATOL + band_factor * max(2e-6 * scale, 0.25 * floor.get(k, 0.0))
         report[k] = strict
-        assert strict > min_strict, f"{k}: only {strict:.4f} within 1e-5/1e-4"
-        assert close(a, b, atol=band, rtol=1e-3).all(), f"{k}: max abs diff {np.abs(a - b).max():.3e} (scale {scale:.3e}, fp32 floor {floor.get(k)})"
+        chk(strict > min_strict, k, "strict fraction", strict, min_strict, f"{k}: only {strict:.4f} within 1e-5/1e-4")
+        chk(close(a, b, atol=band, rtol=1e-3).all(), k, "band", np.abs(a - b).max(), band,
+            f"{k}: max abs diff {np.abs(a - b).max():.3e} (scale {scale:.3e}, fp32 floor {floor.get(k)})")
         if k in g64 and ill_mask is None:
             c = g64[k].reshape(got[k].shape)[rows]
             e_hip, e_ref = np.abs(a.astype(np.float64) - c), np.abs(b.astype(np.float64) - c)
-            assert np.sqrt((e_hip ** 2).mean()) <= rms_factor * np.sqrt((e_ref ** 2).mean()) + 1e-7, f"{k}: rms error vs fp64 worse than the fp32 oracle's"
-            assert e_hip.max() <= max_factor * e_ref.max() + ATOL, f"{k}: max error vs fp64 {e_hip.max():.3e} vs oracle's {e_ref.max():.3e}"
+            r_hip, r_ref = np.sqrt((e_hip ** 2).mean()), np.sqrt((e_ref ** 2).mean())
+            chk(r_hip <= rms_factor * r_ref + 1e-7, k, "rms vs fp64 / oracle32's", r_hip / (r_ref + 1e-30), rms_factor, f"{k}: rms error vs fp64 worse than the fp32 oracle's")
+            chk(e_hip.max() <= max_factor * e_ref.max() + ATOL, k, "max vs fp64 / oracle32's", e_hip.max() / (e_ref.max() + 1e-30), max_factor,
+                f"{k}: max error vs fp64 {e_hip.max():.3e} vs oracle's {e_ref.max():.3e}")
     return report
 
 
