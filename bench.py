@@ -142,6 +142,8 @@ def main():
     def step():
         vm, pm, cp = cams[counter[0] % nviews]
         counter[0] += 1
+        if bucket is not None and args.exchange == "factored":
+            bucket.set_view(cp)      # lets the all-gather of the dL/dRGB rows start under the per-Gaussian backward kernel
         fw = C.rasterize_gaussians(s.bg, s.means3D, e, s.opacities, s.scales, s.rotations, 1.0, e, vm, pm, s.tanfovx,
                                    s.tanfovy, s.kernel_size, H, W, s.shs, s.sh_degree, cp, False, s.require_coord,
                                    s.require_depth, False)

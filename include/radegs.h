@@ -138,6 +138,12 @@ typedef struct RadegsBwdArgs {
    * dL_dmeans3D / dL_dscales / dL_drotations.  Negligible (~1e-6 of the conic term) at the reference's default kernel_size = 0.
    * 1: the derivative the formulas intend (combined_opacity = opacity*coef) -- what an upstream fix would compute. */
   int opacity_grad_intended;
+  /* Optional hand-off for a view-parallel caller (needs dL_drgb_clamped): dL_drgb_clamped is final as soon as the blend backward has
+   * run, one kernel before everything else -- it is then written by a small kernel of its own and `drgb_ready(drgb_ready_user)` is
+   * called ON THE HOST once that kernel is queued on `stream`, BEFORE the per-Gaussian backward (~0.16 ms at 1M Gaussians) is queued:
+   * the caller records an event there and starts its all-gather of these 12-byte rows on another stream, under that kernel. */
+  void (*drgb_ready)(void* user);
+  void* drgb_ready_user;
 } RadegsBwdArgs;
 
 /* `accum_alloc` provides the per-Gaussian accumulation scratch (64 or 128 B per Gaussian). */
@@ -199,7 +205,8 @@ size_t radegs_binning_bytes(int R);
 /* Test/inspection hook: copy a named private array out of the state buffers into `dst`
  * (device memory, dst_bytes large enough).  Names: "point_list" u32[R], "ranges" u32[2*tiles],
  * "n_contrib" u32[2*H*W], "tiles_touched" u32[P], "splat_a" f32[P,16], "splat_b" f32[P,12],
- * "clamped" u8[P], "depth_key" u32[P].  Returns bytes copied or a negative error. */
+ * "clamped" u8[P] (bits 0..2: SH channel clamped at 0; bit 3: the eigen-solver converged), "depth_key" u32[P], "blk_count" /
+ * "blk_consumed" u32[8*tiles] (entry streams).  Returns bytes copied or a negative error. */
 long long radegs_debug_export(const char* name, int P, int R, int width, int height, int require_coord, const void* geom_buffer,
                               const void* binning_buffer, const void* image_buffer, void* dst, size_t dst_bytes, void* stream);
 
@@ -220,6 +227,12 @@ void radegs_profile_stride(int every);
 int radegs_profile_num_stages(void);
 const char* radegs_profile_stage_name(int i);
 int radegs_profile_collect(float* ms_total, int* count, int n);
+
+/* The library remembers, by ADDRESS, which image-state buffers hold entry streams written by their forward (radegs_backward replays
+ * them only then; otherwise it runs the tile-wide kernels, which are valid after either forward).  Tell it when such a buffer is
+ * freed or moved, so that an unrelated buffer landing on the same address later is not mistaken for one.  (The Python binding
+ * does this from the tensor's finaliser and on resize.) */
+void radegs_forget_image(const void* image_buffer);
 
 const char* radegs_last_error(void);
 const char* radegs_version(void);

@@ -23,7 +23,8 @@ OUT_DIR = os.path.join(HERE, "diff_gaussian_rasterization")
 OBJ_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(OUT_DIR, "libradegs_hip.so")
 CHECK_LIB = os.path.join(OUT_DIR, "libradegs_prims_check.so")   # test-only: rocPRIM cross-check of the hand-written sorts
-ARCH = "gfx950"
+ARCH = "gfx950"   # the only target: kernels use gfx950's 160 KB LDS (radegs_sort.hip's 32-item scatter needs 70 KB per workgroup), its DPP /
+                  # bank-mask forms and wave64 tilings -- changing this does not give a working gfx90a / gfx942 library
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-fno-slp-vectorize", "-Wno-unused-value", "-I", CSRC]
 UNITS = {

@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(const PreFwdArgs a)
   preprocess_fwd<INTE>(mk3(m[0], m[1], m[2]), a.scales ? a.scales + 3 * (size_t)idx : nullptr,
                  a.rotations ? a.rotations + 4 * (size_t)idx : nullptr, a.cov3D_precomp ? a.cov3D_precomp + 6 * (size_t)idx : nullptr,
                  a.opacities[idx], a.D, a.shs ? a.shs + (size_t)idx * a.M * 3 : nullptr,
-                 a.colors_precomp ? a.colors_precomp + 3 * (size_t)idx : nullptr, cam, s);
+                 a.colors_precomp ? a.colors_precomp + 3 * (size_t)idx : nullptr, cam, s, reinterpret_cast<float*>(a.eig + 3 * (size_t)idx));
   a.radii[idx] = s.radius;
   a.tiles_touched[idx] = (uint32_t)s.tiles;
   a.rect[idx] = s.radius > 0 ? s.rect : 0u;
@@ -99,12 +99,6 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(const PreFwdArgs a)
       rb[2] = make_float4(s.vp[2], 0.f, 0.f, 0.f);
     }
     a.clamped[idx] = (uint8_t)(s.clamped | (s.eigD != 0 ? 8u : 0u));   // bits 0..2: SH clamp flags; bit 3: eigen-solver converged
-    {
-      float4* re = a.eig + 3 * (size_t)idx;
-      re[0] = make_float4(s.eig[0], s.eig[1], s.eig[2], s.eig[3]);
-      re[1] = make_float4(s.eig[4], s.eig[5], s.eig[6], s.eig[7]);
-      re[2] = make_float4(s.eig[8], s.eig[9], s.eig[10], s.eig[11]);
-    }
     if constexpr (INTE) {
       float4* ri = a.inte_rec + 2 * (size_t)idx;
       ri[0] = make_float4(s.icr[0], s.icr[1], s.icr[2], s.icr[3]);
@@ -1437,7 +1431,24 @@ struct PreBwdArgs {
   float* dL_drot;
   float* dL_drgb_clamped;  // optional [P,3]: dL/dRGB with the clamp mask applied (the view-parallel factored exchange)
   int opacity_grad_intended;  // RadegsBwdArgs::opacity_grad_intended (include/radegs.h)
+  int drgb_done;              // dL_drgb_clamped was already written by drgb_clamped_kernel (RadegsBwdArgs::drgb_ready)
 };
+
+// dL/dRGB with the SH clamp mask applied, straight from the blend backward's sums (the first three floats of every accumulator
+// record): what the factored view-parallel exchange all-gathers.  Its own kernel so that the collective can start one kernel
+// earlier, under preprocess_bwd_kernel (RadegsBwdArgs::drgb_ready).
+__global__ void __launch_bounds__(256) drgb_clamped_kernel(int P, const int* __restrict__ radii, const uint8_t* __restrict__ clamped,
+                                                           const float* __restrict__ acc, int rec, float* __restrict__ out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P) return;
+  float r = 0.f, g = 0.f, b = 0.f;
+  if (radii[idx] > 0) {
+    const unsigned cl = (unsigned)clamped[idx];
+    const float* a = acc + (size_t)idx * rec;
+    r = a[0] * ((cl & 1u) ? 0.f : 1.f); g = a[1] * ((cl & 2u) ? 0.f : 1.f); b = a[2] * ((cl & 4u) ? 0.f : 1.f);
+  }
+  out[3 * (size_t)idx] = r; out[3 * (size_t)idx + 1] = g; out[3 * (size_t)idx + 2] = b;
+}
 
 // 128 Gaussians per block.  The (P,M,3) SH tensor and its gradient are 192-byte rows at SH degree 3: read or
 // written by one thread each they would be 64 different cache lines per instruction.  The block therefore
@@ -1484,7 +1495,7 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
 #pragma unroll
       for (int c = 0; c < 4; c++) a.dL_drot[4 * i + c] = 0;
       if (row) for (int c = 0; c < rowf; c++) row[c] = 0;
-      if (a.dL_drgb_clamped) { a.dL_drgb_clamped[3 * i] = 0; a.dL_drgb_clamped[3 * i + 1] = 0; a.dL_drgb_clamped[3 * i + 2] = 0; }
+      if (a.dL_drgb_clamped && !a.drgb_done) { a.dL_drgb_clamped[3 * i] = 0; a.dL_drgb_clamped[3 * i + 1] = 0; a.dL_drgb_clamped[3 * i + 2] = 0; }
     } else {
       const Camera cam = load_camera(a.cam);
       SplatAcc acc;
@@ -1557,7 +1568,7 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
         a.dL_dscale[3 * i + c] = o.dscale[c];
       }
       a.dL_dopacity[i] = o.dopacity;
-      if (a.dL_drgb_clamped) {
+      if (a.dL_drgb_clamped && !a.drgb_done) {
         const unsigned cl = (unsigned)a.clamped[idx] & 7u;
 #pragma unroll
         for (int c = 0; c < 3; c++) a.dL_drgb_clamped[3 * i + c] = acc.dcolor[c] * (((cl >> c) & 1u) ? 0.f : 1.f);

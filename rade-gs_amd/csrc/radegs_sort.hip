@@ -111,6 +111,9 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const uint32_t* _
   __shared__ uint32_t scan_tmp[4];
   __shared__ uint32_t lds_k[BLOCK_ITEMS];     // the block's items reordered by digit (stable), so that the global
   __shared__ uint32_t lds_v[BLOCK_ITEMS];     // writes below go out in contiguous per-digit runs
+  // ITEMS = 32 (tens of millions of items, C5): 2 x 32 KB + 6 KB of counters = 70 KB of LDS per workgroup -- above the 64 KB of every
+  // AMD architecture before gfx950 (160 KB per CU).  This library is built for gfx950 only (build.py: ARCH).
+  static_assert(2 * BLOCK_ITEMS * sizeof(uint32_t) + 8 * kBins * sizeof(uint32_t) <= 160 * 1024, "scatter_kernel: LDS footprint exceeds gfx950's 160 KB");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   digit_base[tid] = block256_exclusive(totals[tid], scan_tmp) + hist[(size_t)tid * nblocks + blockIdx.x];
 #pragma unroll

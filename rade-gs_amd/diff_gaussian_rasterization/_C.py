@@ -15,6 +15,7 @@ There is NO CPU path and no fallback: a missing library or a non-GPU tensor rais
 import ctypes
 import os
 import threading
+import weakref
 
 import torch
 
@@ -57,7 +58,8 @@ class RadegsBwdArgs(ctypes.Structure):
                 ("dL_dmean3D", ctypes.c_void_p), ("dL_dcov3D", ctypes.c_void_p), ("dL_dsh", ctypes.c_void_p),
                 ("dL_dscale", ctypes.c_void_p), ("dL_drot", ctypes.c_void_p),
                 ("require_coord", ctypes.c_int), ("require_depth", ctypes.c_int), ("debug", ctypes.c_int),
-                ("dL_drgb_clamped", ctypes.c_void_p), ("opacity_grad_intended", ctypes.c_int)]
+                ("dL_drgb_clamped", ctypes.c_void_p), ("opacity_grad_intended", ctypes.c_int),
+                ("drgb_ready", ctypes.c_void_p), ("drgb_ready_user", ctypes.c_void_p)]
 
 
 class RadegsIntegrateArgs(ctypes.Structure):
@@ -75,7 +77,7 @@ class RadegsIntegrateArgs(ctypes.Structure):
 
 # every symbol include/radegs.h declares
 EXPORTED_SYMBOLS = ("radegs_forward", "radegs_backward", "radegs_mark_visible", "radegs_integrate", "radegs_sh_grad_from_views", "radegs_geometry_bytes", "radegs_image_bytes",
-                    "radegs_binning_bytes", "radegs_debug_export", "radegs_last_error", "radegs_version", "radegs_profile_enable",
+                    "radegs_binning_bytes", "radegs_debug_export", "radegs_forget_image", "radegs_last_error", "radegs_version", "radegs_profile_enable",
                     "radegs_profile_select", "radegs_profile_stride", "radegs_binning_stats", "radegs_profile_num_stages", "radegs_profile_stage_name", "radegs_profile_collect",
                     # fused pre/post steps (bound in graphics_utils.py / gaussian_model_ops.py)
                     "radegs_normals_forward", "radegs_normals_backward", "radegs_normal_loss_scratch_bytes",
@@ -126,6 +128,10 @@ def _grad_allocator_for(dev):
 # dL/dRGB (clamp mask applied) -- and (b) return SKIP_GRAD for "dL_dsh": the (P,M,3) SH gradient is then not written and
 # comes back as None (it is basis(dir) x dL_drgb_clamped; view_parallel.FactoredGradExchange rebuilds the batch sum).
 SKIP_GRAD = object()
+# (c) if the allocator OBJECT has a method `drgb_ready()` (the allocator is then a bound method of it), the backward calls it on the
+# host as soon as the kernel that writes dL_drgb_clamped is queued -- before the per-Gaussian backward -- so that an all-gather of
+# those rows can run under that kernel (include/radegs.h::RadegsBwdArgs.drgb_ready).
+_READY_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
 
 
 def library():
@@ -156,6 +162,8 @@ def library():
         L.radegs_debug_export.restype = ctypes.c_longlong
         L.radegs_debug_export.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.radegs_forget_image.restype = None
+        L.radegs_forget_image.argtypes = [ctypes.c_void_p]
         L.radegs_last_error.restype = ctypes.c_char_p
         L.radegs_version.restype = ctypes.c_char_p
         L.radegs_binning_stats.restype = None
@@ -201,17 +209,32 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _forget_image(holder):
+    """The native side remembers which image-state buffers hold entry streams by ADDRESS (the backward replays them only for a
+    buffer whose forward wrote them).  An address must leave that set when its buffer moves or dies, or a later, unrelated buffer
+    landing on it would be taken for a stream image: called on resize and from the tensor's finaliser."""
+    if holder[0] and _lib is not None:
+        _lib.radegs_forget_image(ctypes.c_void_p(holder[0]))
+    holder[0] = 0
+
+
 class _Resizable:
     """uint8 device tensor grown on request from the native side (the resize lambda of
-    DGR/rasterize_points.cu:27-33)."""
+    DGR/rasterize_points.cu:27-33).  image=True: the tensor is an image-state buffer (see _forget_image)."""
 
-    def __init__(self, device):
+    def __init__(self, device, image=False):
         self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
         self.error = None
+        holder = [0]
+        if image:
+            weakref.finalize(self.tensor, _forget_image, holder)
 
         def _cb(_user, nbytes):
             try:
                 self.tensor.resize_(int(nbytes))
+                if image and self.tensor.data_ptr() != holder[0]:
+                    _forget_image(holder)
+                    holder[0] = self.tensor.data_ptr()
                 return self.tensor.data_ptr()
             except Exception as ex:  # surfaces as RADEGS_ERR_ALLOC
                 self.error = ex
@@ -225,21 +248,19 @@ class _Resizable:
         self.cb = None
 
 
-_ZERO_MAPS = {}
-
-
-def _zero_map(shape, device):
-    """An all-zero output map for an output the call does not produce (the reference returns torch.full(0) maps,
-    rasterize_points.cu:71-77).  The tensor is kept and handed out again (as a fresh alias) while nobody has written to it --
-    its version counter tells -- instead of a 25 MB fill per map and call."""
-    key = (device, tuple(shape))
-    ent = _ZERO_MAPS.get(key)
-    if ent is None or ent[0]._version != ent[1]:
-        if len(_ZERO_MAPS) > 16:
-            _ZERO_MAPS.clear()
-        t = torch.zeros(shape, dtype=torch.float32, device=device)
-        ent = _ZERO_MAPS[key] = (t, t._version)
-    return ent[0].detach()
+def _zero_maps(channels, H, W, device):
+    """All-zero maps for the outputs a call does not produce (the reference returns torch.full(0) maps whatever the flags,
+    rasterize_points.cu:71-77): FRESH memory every call, like the reference -- one zero-filled allocation cut into disjoint views,
+    so a caller editing one map in place touches neither the other maps nor any later call (one ~6 us fill at 1080p instead of five)."""
+    total = sum(channels)
+    if total == 0:
+        return []
+    flat = torch.zeros((total, H, W), dtype=torch.float32, device=device)
+    out, off = [], 0
+    for c in channels:
+        out.append(flat[off:off + c])
+        off += c
+    return out
 
 
 def _stream(device):
@@ -259,17 +280,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     fo = dict(dtype=torch.float32, device=dev)
     live = P != 0
 
-    def out(c, written):
-        return torch.empty((c, H, W), **fo) if (live and written) else _zero_map((c, H, W), dev)
-
     geo = require_coord or require_depth
-    out_color = out(3, True)
-    out_depth, out_mdepth = out(1, require_depth), out(1, require_depth)
-    out_coord, out_mcoord = out(3, require_coord), out(3, require_coord)
-    out_alpha = out(1, True)
-    out_normal = out(3, geo)
+    # (channels, produced by this call) in the order color, depth, mdepth, coord, mcoord, alpha, normal
+    spec = [(3, True), (1, require_depth), (1, require_depth), (3, require_coord), (3, require_coord), (1, True), (3, geo)]
+    zeros = iter(_zero_maps([c for c, w in spec if not (live and w)], H, W, dev))
+    maps = [torch.empty((c, H, W), **fo) if (live and w) else next(zeros) for c, w in spec]
+    out_color, out_depth, out_mdepth, out_coord, out_mcoord, out_alpha, out_normal = maps
     radii = torch.empty(P, dtype=torch.int32, device=dev) if live else torch.zeros(P, dtype=torch.int32, device=dev)
-    geom, binning, img = _Resizable(dev), _Resizable(dev), _Resizable(dev)
+    geom, binning, img = _Resizable(dev), _Resizable(dev), _Resizable(dev, image=True)
     rendered = 0
     if live:
         bg, m3 = _f32(background, "bg"), _f32(means3D, "means3D")
@@ -339,18 +357,30 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         if not sc is None and rot is None:
             raise RuntimeError("scales given without rotations")
         acc = _Resizable(dev)
+        ready_cb, ready_err = None, []
+        owner = getattr(grad_alloc, "__self__", None)
+        if drgb is not None and owner is not None and callable(getattr(owner, "drgb_ready", None)) and getattr(owner, "early_drgb", False):
+            def _ready(_user, _owner=owner):
+                try:
+                    _owner.drgb_ready()
+                except Exception as ex:  # noqa: BLE001 -- must not unwind through the C frame
+                    ready_err.append(ex)
+            ready_cb = _READY_FN(_ready)
         a = RadegsBwdArgs(P, int(degree), M, int(R), W, H, _ptr(bg), _ptr(m3), _ptr(shs), _ptr(col), _ptr(al), _ptr(sc), _ptr(rot),
                           _ptr(cov), _ptr(vm), _ptr(pm), _ptr(cp), float(scale_modifier), float(tan_fovx), float(tan_fovy),
                           float(kernel_size), _ptr(rad), _ptr(nm), _ptr(gb) if gb.numel() else None, _ptr(bb) if bb.numel() else None,
                           _ptr(ib) if ib.numel() else None, _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(g[4]), _ptr(g[5]),
                           _ptr(g[6]), _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
                           _ptr(dL_dsh) if (M and dL_dsh is not None) else None, _ptr(dL_dscales), _ptr(dL_drotations),
-                          int(bool(require_coord)), int(bool(require_depth)), int(bool(debug)), _ptr(drgb), int(bool(OPACITY_GRAD_INTENDED)))
+                          int(bool(require_coord)), int(bool(require_depth)), int(bool(debug)), _ptr(drgb), int(bool(OPACITY_GRAD_INTENDED)),
+                          ctypes.cast(ready_cb, ctypes.c_void_p) if ready_cb is not None else None, None)
         with torch.cuda.device(dev):
             rc = L.radegs_backward(ctypes.byref(a), acc.cb, None, _stream(dev))
         acc.release()
         if acc.error is not None:
             raise acc.error
+        if ready_err:
+            raise ready_err[0]
         _check(rc, "radegs_backward")
         if KEEP_ACC:
             global LAST_ACC

@@ -111,7 +111,12 @@ class FactoredGradExchange:
         here    all-reduce  44 B + all-gather (N-1) * 12 B        = 161 B per Gaussian at N = 8
     The result equals the plain all-reduce up to fp32 summation order.  GPU only (the rebuild is a HIP kernel).
 
-    Usage: `_C.set_grad_allocator(device, ex.allocator)` before the backward; `ex.exchange(means3D, campos)` after it."""
+    Overlap: the dL/dRGB rows are final one kernel before the rest of the backward (`drgb_ready`, called by the backward on the host
+    between the two kernels): their all-gather -- the larger share of the bytes at N = 8 -- is started there on a side stream and
+    runs under the per-Gaussian backward kernel; `exchange()` then only issues the 44-B all-reduce and waits.
+
+    Usage: `_C.set_grad_allocator(device, ex.allocator)` before the backward; `ex.set_view(campos)` if the all-gather should start
+    early; `ex.exchange(means3D, campos)` after the backward."""
 
     SMALL = ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations")
 
@@ -131,6 +136,32 @@ class FactoredGradExchange:
         self.gathered = torch.empty((self.world, P, 3), dtype=torch.float32, device=device)
         self.campos_all = torch.empty((self.world, 3), dtype=torch.float32, device=device)
         self.dL_dsh = torch.empty((P, M, 3), dtype=torch.float32, device=device)
+        self.device = torch.device(device)
+        self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._early = None        # (handles, event) of an all-gather started from drgb_ready()
+        self._campos = None
+
+    def set_view(self, campos):
+        """The camera position of the view about to be differentiated: lets drgb_ready() start the all-gathers early."""
+        self._campos = campos.reshape(1, 3).to(torch.float32).contiguous()
+
+    @property
+    def early_drgb(self):
+        """True when the backward should write the dL/dRGB rows with their own early kernel and call drgb_ready()."""
+        return self._campos is not None and self._side is not None and dist.is_available() and dist.is_initialized()
+
+    def drgb_ready(self):
+        """Called by `_C.rasterize_gaussians_backward` on the host once the kernel that writes the dL/dRGB rows is queued (and the
+        per-Gaussian backward is not yet): start their all-gather on the side stream."""
+        if self._campos is None or self._side is None or not (dist.is_available() and dist.is_initialized()):
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ev)
+            h1 = dist.all_gather_into_tensor(self.gathered.view(-1, 3), self.drgb, group=self.group, async_op=True)
+            h2 = dist.all_gather_into_tensor(self.campos_all, self._campos, group=self.group, async_op=True)
+        self._early = (h1, h2)
 
     def allocator(self, name, shape, dtype, device):
         if name == "dL_drgb_clamped":
@@ -144,8 +175,12 @@ class FactoredGradExchange:
         scale = 1.0
         if dist.is_available() and dist.is_initialized():
             # output in the concatenated form (world*P, 3): the layout every backend's all_gather_into_tensor accepts
-            h1 = dist.all_gather_into_tensor(self.gathered.view(-1, 3), self.drgb, group=self.group, async_op=True)
-            h2 = dist.all_gather_into_tensor(self.campos_all, campos.reshape(1, 3).to(torch.float32).contiguous(), group=self.group, async_op=True)
+            if self._early is not None:      # started under the per-Gaussian backward (drgb_ready)
+                h1, h2 = self._early
+                self._early, self._campos = None, None
+            else:
+                h1 = dist.all_gather_into_tensor(self.gathered.view(-1, 3), self.drgb, group=self.group, async_op=True)
+                h2 = dist.all_gather_into_tensor(self.campos_all, campos.reshape(1, 3).to(torch.float32).contiguous(), group=self.group, async_op=True)
             dist.all_reduce(self.small, op=dist.ReduceOp.SUM, group=self.group)
             h1.wait()
             h2.wait()

@@ -45,6 +45,14 @@ def main():
         got = ex.exchange(s.means3D, s.campos, average=True)
         torch.cuda.synchronize(dev)
         res["factored"] = {k: rel(got[k], want[k]) for k in want}
+        # 1b. the same with the all-gather started early, from the backward's drgb_ready hook, on the side stream
+        ex.set_view(s.campos)
+        assert ex.early_drgb
+        _backward(C, s, g, e)
+        res["early_started"] = ex._early is not None
+        got = ex.exchange(s.means3D, s.campos, average=True)
+        torch.cuda.synchronize(dev)
+        res["factored_early"] = {k: rel(got[k], want[k]) for k in want}
         # 2. plain bucket: one all-reduce of 236 B/Gaussian written in place by the backward
         bk = GradBucket(P, M, dev)
         C.set_grad_allocator(dev, bk.allocator)

@@ -395,17 +395,36 @@ def test_speculative_binning_matches_exact_path():
 
 @pytest.mark.gpu
 def test_unproduced_maps_are_zero_call_after_call():
-    """Maps a mode does not produce are cached zero tensors (handed out again while nobody wrote to them): they must be zeros on
-    every call, also after the mode changed in between, and a caller that writes into one must not poison the next call."""
+    """Maps a mode does not produce are FRESH zero tensors on every call, as the reference's torch.full(0) maps are
+    (rasterize_points.cu:71-77): zeros also after the mode changed in between, no storage shared between two calls or between two
+    maps of one call, and a caller that writes into one poisons nothing."""
     from gpu_util import HipRun
-    for rnd, (coord, depth) in enumerate([(False, True), (True, True), (False, True), (True, False), (False, True)]):
+    held = []
+    for rnd, (coord, depth) in enumerate([(False, True), (True, True), (False, True), (True, False), (False, False), (False, True)]):
         s = make_scene(3000, 203, 131, sh_degree=1, mu_px=2.5, seed=70 + rnd, kernel_size=0.1, require_coord=coord, require_depth=depth, pose="random")
         color, radii, co, mco, de, mde, alpha, normal = HipRun(s, _dev()).forward()
         if not coord:
             assert not bool(co.any()) and not bool(mco.any())
-            co.detach().add_(1.0)   # a caller scribbling over its map: the cache must notice (version counter) and not reuse it
+            co.detach().add_(1.0)                       # a caller scribbling over its map ...
+            assert not bool(mco.any())                  # ... touches neither its sibling ...
+            for old in held:                            # ... nor what earlier calls handed out
+                assert not bool(old.any())
+            held.append(mco.detach())
         if not depth:
             assert not bool(de.any()) and not bool(mde.any())
+        if not (coord or depth):
+            assert not bool(normal.any())
+
+
+def test_stream_byte_budget_falls_back_to_the_tile_wide_kernels(monkeypatch):
+    """RADEGS_STREAMS_MAX_MB: above the budget the launcher does not ask for entry-stream storage (~96 B per instance of capacity);
+    the tile-wide kernels then run on the plain image state -- same results."""
+    import diff_gaussian_rasterization._C as C
+    monkeypatch.setenv("RADEGS_STREAMS_MAX_MB", "0")
+    s = make_scene(6000, 232, 168, sh_degree=2, mu_px=2.0, seed=66, kernel_size=0.1, require_coord=False, require_depth=True, pose="random")
+    o, h = check_forward(s)
+    assert h.state[11].numel() == C.library().radegs_image_bytes(s.W, s.H)      # no stream storage behind the image state
+    check_backward(s, o, seed=66)
 
 
 @pytest.mark.gpu

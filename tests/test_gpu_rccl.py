@@ -39,7 +39,8 @@ def test_exchange_collectives_run_through_rccl_and_match_the_plain_backward(tmp_
     res = json.load(open(out))
     assert res["ok"], res
     assert res["backend"] == "nccl" and res["world"] == 1
-    for mode in ("factored", "bucket", "packed"):
+    assert res["early_started"]          # the backward called drgb_ready() and the all-gather was queued under its last kernel
+    for mode in ("factored", "factored_early", "bucket", "packed"):
         for k, v in res[mode].items():
             # two backward runs differ by the order of their float atomics, the factored SH rebuild by summation order; the geometry
             # gradients of the default (reference-executed) backward move by up to ~1e-3 of their scale with that order at kernel_size 0
