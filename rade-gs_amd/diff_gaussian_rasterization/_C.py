@@ -213,8 +213,11 @@ def _forget_image(holder):
     """The native side remembers which image-state buffers hold entry streams by ADDRESS (the backward replays them only for a
     buffer whose forward wrote them).  An address must leave that set when its buffer moves or dies, or a later, unrelated buffer
     landing on it would be taken for a stream image: called on resize and from the tensor's finaliser."""
-    if holder[0] and _lib is not None:
-        _lib.radegs_forget_image(ctypes.c_void_p(holder[0]))
+    try:
+        if holder[0] and _lib is not None:
+            _lib.radegs_forget_image(ctypes.c_void_p(holder[0]))
+    except Exception:   # interpreter shutdown: the library may already be gone; nothing left to protect then
+        pass
     holder[0] = 0
 
 

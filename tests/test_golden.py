@@ -49,7 +49,9 @@ def test_hip_matches_golden(case):
     assert np.array_equal(h.export("ranges", torch.int32, 2 * ntiles).view(np.uint32), want["ranges"][: 2 * ntiles])
     assert np.array_equal(h.export("n_contrib", torch.int32, 2 * s.H * s.W).view(np.uint32)[: s.H * s.W], want["n_contrib"][: s.H * s.W])
     for k, t in (("color", st[1]), ("coord", st[2]), ("mcoord", st[3]), ("alpha", st[4]), ("normal", st[5]), ("depth", st[6]), ("mdepth", st[7])):
-        assert close(t.cpu().numpy(), want[k]).all(), k
+        a_, b_ = t.cpu().numpy(), want[k]
+        bad = ~close(a_, b_)
+        assert not bad.any(), f"{k}: {int(bad.sum())} elements outside 1e-5/1e-4, max |diff| {float(np.abs(a_ - b_).max()):.3e}, first at {np.argwhere(bad)[:4].tolist()}"
     h2 = HipRun(s, "cuda:0")
     h2.forward()
     got = h2.backward(upstream_grads(s, make_golden.CASES[case]["seed"]))
