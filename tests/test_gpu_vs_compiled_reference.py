@@ -1,6 +1,6 @@
 """The HIP path against the COMPILED REFERENCE directly (oracle/_ref: the reference's own forward.cu / backward.cu / rasterizer_impl.cu
 built for the host, tests/test_ref_parity.py), with no hand-written oracle in between, at a size beyond the committed golden vectors:
-a C2-shaped scene of 100 000 Gaussians at 608 x 342 and C2 itself at its named size (1M Gaussians, 1920 x 1080).  The prebuilt library travels to the GPU box with the snapshot (it is built where
+a C2-shaped scene of 100 000 Gaussians at 608 x 342 and every BASELINE config with a GPU (C2, C3, C4, C5) at its named size.  The prebuilt library travels to the GPU box with the snapshot (it is built where
 /root/reference exists); without it the test skips and tests/test_golden.py's reference-produced vectors carry the statement."""
 import numpy as np
 import pytest
@@ -14,14 +14,17 @@ pytestmark = [pytest.mark.gpu, pytest.mark.executed_grad,
               pytest.mark.skipif(not ref.available(), reason="oracle/_ref/libradegs_ref.so was not built (no /root/reference on the build host)")]
 
 
-@pytest.mark.parametrize("coord,depth,ks,full", [(False, True, 0.0, False), (True, True, 0.1, False), (False, True, 0.0, True)],
-                         ids=["100k_depth_ks0", "100k_both_ks0.1", "C2_full_size"])
+@pytest.mark.parametrize("coord,depth,ks,full", [(False, True, 0.0, None), (True, True, 0.1, None), (False, True, 0.0, "C2"),
+                                                 (False, True, 0.0, "C3"), (True, False, 0.0, "C4"), (False, True, 0.0, "C5")],
+                         ids=["100k_depth_ks0", "100k_both_ks0.1", "C2_full_size", "C3_full_size", "C4_full_size", "C5_full_size"])
 def test_hip_equals_the_references_own_code(coord, depth, ks, full):
     from gpu_util import HipRun
     from synth_scene import make_config
     from test_ref_parity import ref_for
-    if full:    # BASELINE.json configs[1] at its named size: 1M Gaussians, 1920x1080, SH3 -- ~7 s of the reference's code on the host cores
-        s = make_config("C2")
+    if full:    # a BASELINE.json config at its named size through the reference's own code on the host cores (C2: ~7 s, C5: minutes)
+        if full in ("C4", "C5") and __import__("os").environ.get("RADEGS_SKIP_FULL_ORACLE", "0") == "1":
+            pytest.skip("RADEGS_SKIP_FULL_ORACLE=1")
+        s = make_config(full)
     else:
         s = make_scene(100_000, 608, 342, sh_degree=3, mu_px=1.5, seed=7, kernel_size=ks, require_coord=coord, require_depth=depth)
     ref.set_exp("spec")
@@ -51,6 +54,7 @@ def test_hip_equals_the_references_own_code(coord, depth, ks, full):
         # ---- gradients of the backward the reference executes (its float atomics land in another order than ours: the band is the
         # fp32 conditioning of the sums, as everywhere else; geometry gradients carry the slip term's order noise, conftest) ----
         g = upstream_grads(s, 7)
+        del want
         r.backward(g["color"], g["coord"], g["mcoord"], g["depth"], g["mdepth"], g["alpha"], g["normal"])
         want_g = r.grads()
         h2 = HipRun(s, "cuda:0")
@@ -66,11 +70,11 @@ def test_hip_equals_the_references_own_code(coord, depth, ks, full):
             scale = float(np.abs(b).max()) + 1e-30
             assert frac_close(got[k], b) > 0.97, (k, frac_close(got[k], b))
             # at kernel_size 0 the slip term is a cancellation residue scaled by an accumulated sum: the reference's own value moves by
-            # up to ~1e-3 of the scale with the order of its atomics (more in the tail of a million Gaussians), so: all but 1e-5 of
-            # the elements inside 3e-3 of the scale, none further than 5e-2
+            # up to ~1e-3 of the scale with the order of its atomics (more in the tail of a million Gaussians and of C5's long sums), so:
+            # all but 1e-4 of the elements inside 3e-3 of the scale, none further than 5e-2
             d = np.abs(got[k].astype(np.float64) - b)
             inside = d <= ATOL + 3e-3 * scale + 1e-3 * np.abs(b)
-            assert inside.mean() >= 1.0 - 1e-5, (k, float(inside.mean()), float(d.max()), scale)
+            assert inside.mean() >= 1.0 - 1e-4, (k, float(inside.mean()), float(d.max()), scale)
             assert d.max() <= 5e-2 * scale, (k, float(d.max()), scale)
     finally:
         ref.set_exp("libm")
