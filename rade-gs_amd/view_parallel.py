@@ -6,6 +6,7 @@ BASELINE.json's north_star asks for.  The six gradient tensors (xyz, SH, opacity
 = 59 floats = 236 B per Gaussian) are packed into ONE flat bucket so a single RCCL all-reduce moves
 them over xGMI; with `backend="gloo"` the same code runs on CPU tensors (tests/test_dist_gloo.py).
 """
+import os
 from typing import Dict, Iterable, List
 
 import torch
@@ -148,19 +149,25 @@ class FactoredGradExchange:
     @property
     def early_drgb(self):
         """True when the backward should write the dL/dRGB rows with their own early kernel and call drgb_ready()."""
-        return self._campos is not None and self._side is not None and dist.is_available() and dist.is_initialized()
+        if os.environ.get("RADEGS_EARLY_ALLGATHER", "1") == "0":     # escape hatch: issue every collective from exchange()
+            return False
+        return self._campos is not None and dist.is_available() and dist.is_initialized()
 
     def drgb_ready(self):
         """Called by `_C.rasterize_gaussians_backward` on the host once the kernel that writes the dL/dRGB rows is queued (and the
         per-Gaussian backward is not yet): start their all-gather on the side stream."""
-        if self._campos is None or self._side is None or not (dist.is_available() and dist.is_initialized()):
+        if not self.early_drgb:
             return
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(self._side):
-            self._side.wait_event(ev)
+        if self._side is None:      # CPU tensors (gloo): asynchronous collectives need no stream
             h1 = dist.all_gather_into_tensor(self.gathered.view(-1, 3), self.drgb, group=self.group, async_op=True)
             h2 = dist.all_gather_into_tensor(self.campos_all, self._campos, group=self.group, async_op=True)
+        else:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev)
+                h1 = dist.all_gather_into_tensor(self.gathered.view(-1, 3), self.drgb, group=self.group, async_op=True)
+                h2 = dist.all_gather_into_tensor(self.campos_all, self._campos, group=self.group, async_op=True)
         self._early = (h1, h2)
 
     def allocator(self, name, shape, dtype, device):

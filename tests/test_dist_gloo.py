@@ -143,7 +143,20 @@ def _factored_worker(rank, world, port, out_dir):
         v.copy_(torch.randn(v.shape, generator=g))
     small_before = ex.small.clone()
     ex.allocator("dL_drgb_clamped", (P, 3), torch.float32, None).copy_(drgb)
-    out = ex.exchange(means3D, campos, average=True)
+    out = {k: v.clone() for k, v in ex.exchange(means3D, campos, average=True).items()}
+    # the same step with the all-gathers started EARLY, the way the backward's drgb_ready hook starts them (before the small bucket is
+    # final), and the all-reduce issued afterwards from exchange(): same result on every rank
+    for k, v in ex.views.items():
+        v.zero_()
+    ex.set_view(campos)
+    assert ex.early_drgb
+    ex.drgb_ready()
+    assert ex._early is not None
+    ex.small.copy_(small_before)
+    out_early = ex.exchange(means3D, campos, average=True)
+    for k in out:
+        assert torch.equal(out_early[k], out[k]), k
+    assert ex._early is None and not ex.early_drgb
     torch.save({"out": {k: v.clone() for k, v in out.items()}, "small": small_before, "drgb": drgb, "campos": campos, "means3D": means3D},
                os.path.join(out_dir, f"f{rank}.pt"))
     dist.barrier()
