@@ -221,6 +221,12 @@ def _forget_image(holder):
     holder[0] = 0
 
 
+# Test knob (tests/test_gpu_poison.py): every buffer the native side is about to fill -- the produced maps, radii, the three state
+# buffers -- is first overwritten with 0xFF bytes / NaN, so a kernel that reads something this call has not written, or leaves a
+# pixel unwritten, shows up in the results instead of hiding behind whatever the allocator's recycled memory happened to hold.
+_POISON = os.environ.get("RADEGS_DEBUG_POISON", "0") == "1"
+
+
 class _Resizable:
     """uint8 device tensor grown on request from the native side (the resize lambda of
     DGR/rasterize_points.cu:27-33).  image=True: the tensor is an image-state buffer (see _forget_image)."""
@@ -235,6 +241,8 @@ class _Resizable:
         def _cb(_user, nbytes):
             try:
                 self.tensor.resize_(int(nbytes))
+                if _POISON:
+                    self.tensor.fill_(0xFF)
                 if image and self.tensor.data_ptr() != holder[0]:
                     _forget_image(holder)
                     holder[0] = self.tensor.data_ptr()
@@ -290,6 +298,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     maps = [torch.empty((c, H, W), **fo) if (live and w) else next(zeros) for c, w in spec]
     out_color, out_depth, out_mdepth, out_coord, out_mcoord, out_alpha, out_normal = maps
     radii = torch.empty(P, dtype=torch.int32, device=dev) if live else torch.zeros(P, dtype=torch.int32, device=dev)
+    if _POISON and live:
+        for (c, w), m in zip(spec, maps):
+            if w:
+                m.fill_(float("nan"))
+        radii.fill_(-0x01010102)
     geom, binning, img = _Resizable(dev), _Resizable(dev), _Resizable(dev, image=True)
     rendered = 0
     if live:
@@ -334,6 +347,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             if t is not None:
                 assert t.shape == torch.Size(shape) and t.is_contiguous() and t.dtype == torch.float32 and t.device == dev
                 return t
+        if P != 0 and _POISON:
+            return torch.full(shape, float("nan"), **fo)
         return torch.empty(shape, **fo) if P != 0 else torch.zeros(shape, **fo)
 
     dL_dmeans3D, dL_dmeans2D, dL_dcolors = mk("dL_dmeans3D", (P, 3)), mk("dL_dmeans2D", (P, 3)), mk("dL_dcolors", (P, 3))

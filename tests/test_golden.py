@@ -27,6 +27,16 @@ def test_oracle_reproduces_golden(case):
         assert np.array_equal(a.view(np.uint8) if a.dtype.kind == "f" else a, b.view(np.uint8) if b.dtype.kind == "f" else b), k
 
 
+def _dump_state(case, h, st, maps):
+    """Everything a post-mortem of a map mismatch needs: the maps, and the geometry / binning / image state buffers byte for byte
+    (gpurun_out/ travels back from the GPU box)."""
+    root = os.path.join(os.path.dirname(HERE), "gpurun_out", f"golden_state_{case}_{os.getpid()}")
+    os.makedirs(root, exist_ok=True)
+    np.savez_compressed(os.path.join(root, "maps.npz"), **maps)
+    np.savez_compressed(os.path.join(root, "state.npz"), geom=st[9].cpu().numpy(), binning=st[10].cpu().numpy(), image=st[11].cpu().numpy(),
+                        R=np.int64(st[0]), radii=st[8].cpu().numpy())
+
+
 @pytest.mark.gpu
 @pytest.mark.executed_grad
 @pytest.mark.parametrize("case", list(make_golden.CASES))
@@ -48,8 +58,13 @@ def test_hip_matches_golden(case):
     ntiles = ((s.W + 15) // 16) * ((s.H + 15) // 16)
     assert np.array_equal(h.export("ranges", torch.int32, 2 * ntiles).view(np.uint32), want["ranges"][: 2 * ntiles])
     assert np.array_equal(h.export("n_contrib", torch.int32, 2 * s.H * s.W).view(np.uint32)[: s.H * s.W], want["n_contrib"][: s.H * s.W])
-    for k, t in (("color", st[1]), ("coord", st[2]), ("mcoord", st[3]), ("alpha", st[4]), ("normal", st[5]), ("depth", st[6]), ("mdepth", st[7])):
-        a_, b_ = t.cpu().numpy(), want[k]
+    names = ("color", "coord", "mcoord", "alpha", "normal", "depth", "mdepth")
+    maps = {k: t.cpu().numpy() for k, t in zip(names, st[1:8])}
+    wrong = [k for k in names if not close(maps[k], want[k]).all()]
+    if wrong or os.environ.get("RADEGS_GOLDEN_DUMP") == "1":
+        _dump_state(case, h, st, maps)      # the raw state buffers of THIS forward, for a post-mortem next to a good run's
+    for k in names:
+        a_, b_ = maps[k], want[k]
         bad = ~close(a_, b_)
         assert not bad.any(), f"{k}: {int(bad.sum())} elements outside 1e-5/1e-4, max |diff| {float(np.abs(a_ - b_).max()):.3e}, first at {np.argwhere(bad)[:4].tolist()}"
     h2 = HipRun(s, "cuda:0")
