@@ -42,10 +42,9 @@ def test_exchange_collectives_run_through_rccl_and_match_the_plain_backward(tmp_
     assert res["early_started"]          # the backward called drgb_ready() and the all-gather was queued under its last kernel
     for mode in ("factored", "factored_early", "bucket", "packed"):
         for k, v in res[mode].items():
-            # two backward runs differ by the order of their float atomics, the factored SH rebuild by summation order; the geometry
-            # gradients of the default (reference-executed) backward move by up to ~1e-3 of their scale with that order at kernel_size 0
-            # (conftest._gradient_mode) -- the worker runs the product's defaults
-            assert v <= (2e-5 if k in ("dL_dsh", "dL_dopacity") else 3e-3), (mode, k, v)
+            # two backward runs differ by the order of their float atomics, the factored SH rebuild by summation order (the worker
+            # selects the intended derivative, so no slip-term noise rides on the geometry gradients)
+            assert v <= (2e-5 if k in ("dL_dsh", "dL_dopacity") else 1e-3), (mode, k, v)
     assert res["stats_ok"]
 
 
