@@ -91,3 +91,70 @@ def test_fused_step_modules_have_no_cpu_fallback():
         gu.normal_consistency_loss(v, torch.ones(3, 8, 8), torch.ones(1, 8, 8), torch.ones(1, 8, 8))
     with pytest.raises(RuntimeError, match="no CPU implementation"):
         gmo.scaling_n_opacity_with_3D_filter(torch.zeros(4, 3), torch.zeros(4, 1), torch.zeros(4, 1))
+
+
+def _c_lib():
+    import diff_gaussian_rasterization._C as C
+    L = ctypes.CDLL(C._LIB_PATH)
+    L.radegs_last_error.restype = ctypes.c_char_p
+    L.radegs_forward.restype = ctypes.c_int
+    L.radegs_backward.restype = ctypes.c_int
+    for f in (L.radegs_geometry_bytes, L.radegs_image_bytes, L.radegs_binning_bytes):
+        f.restype = ctypes.c_size_t
+    return C, L
+
+
+def test_c_abi_rejects_bad_arguments_before_touching_the_device():
+    """The checks of rasterize_points.cu:60-62 / __init__.py:205-210 live behind the C ABI too (a C caller has no Python layer in front):
+    every rejection below returns before the first HIP call, so it runs without a GPU.  Pointers are never dereferenced here."""
+    C, L = _c_lib()
+    INVALID = -1        # RADEGS_ERR_INVALID_ARG (include/radegs.h)
+    assert re.search(r"#define\s+RADEGS_ERR_INVALID_ARG\s+\(-1\)", open(os.path.join(ROOT, "include", "radegs.h")).read())
+    cb = C._ALLOC_FN(lambda user, n: 0)
+    fake = 0x1000
+
+    def fwd(**over):
+        kw = dict(P=4, D=0, M=1, width=32, height=32, background=fake, means3D=fake, shs=fake, colors_precomp=None, opacities=fake,
+                  scales=fake, rotations=fake, cov3D_precomp=None, viewmatrix=fake, projmatrix=fake, cam_pos=fake, scale_modifier=1.0,
+                  tan_fovx=1.0, tan_fovy=1.0, kernel_size=0.0, prefiltered=0, require_coord=0, require_depth=0, debug=0,
+                  out_color=fake, out_coord=None, out_mcoord=None, out_depth=None, out_mdepth=None, out_alpha=fake, out_normal=None,
+                  radii=fake)
+        kw.update(over)
+        a = C.RadegsFwdArgs(**kw)
+        rc = L.radegs_forward(ctypes.byref(a), cb, None, cb, None, cb, None, None)
+        return rc, L.radegs_last_error().decode()
+
+    assert L.radegs_forward(None, cb, None, cb, None, cb, None, None) == INVALID
+    assert fwd(P=0)[0] == 0                                   # nothing to do, nothing launched (rasterize_points.cu:90)
+    for over, text in ((dict(P=-1), "bad sizes"), (dict(width=0), "bad sizes"), (dict(means3D=None), "missing required tensor"),
+                       (dict(radii=None), "missing required tensor"),
+                       (dict(shs=None), "excatly one of either SHs or precomputed colors"),
+                       (dict(colors_precomp=fake), "excatly one of either SHs or precomputed colors"),
+                       (dict(rotations=None), "exactly one of either scale/rotation pair or precomputed 3D covariance"),
+                       (dict(cov3D_precomp=fake), "exactly one of either scale/rotation pair or precomputed 3D covariance"),
+                       (dict(prefiltered=1), "prefiltered"), (dict(D=2, M=4), "sh_degree needs more SH rows"),
+                       (dict(require_coord=1), "coord outputs missing"), (dict(require_depth=1), "depth outputs missing"),
+                       (dict(require_depth=1, out_depth=fake, out_mdepth=fake), "normal output missing")):
+        rc, msg = fwd(**over)
+        assert rc == INVALID and text in msg, (over, rc, msg)
+    # the backward: state buffers and gradient outputs are checked before anything runs
+    b = C.RadegsBwdArgs()
+    b.P = 3
+    assert L.radegs_backward(ctypes.byref(b), cb, None, None) == INVALID and "state buffers missing" in L.radegs_last_error().decode()
+    b.geom_buffer, b.image_buffer = fake, fake
+    assert L.radegs_backward(ctypes.byref(b), cb, None, None) == INVALID and "gradient outputs missing" in L.radegs_last_error().decode()
+    b.P = 0
+    assert L.radegs_backward(ctypes.byref(b), cb, None, None) == 0
+
+
+def test_state_sizes_are_host_arithmetic():
+    """radegs_*_bytes (the `required<T>` of rasterizer_impl.h:84-91): pure functions of the sizes, monotone, and the image state does not
+    depend on the number of Gaussians."""
+    _, L = _c_lib()
+    g = [L.radegs_geometry_bytes(p, 0) for p in (1, 1000, 1_000_000)]
+    assert g[0] > 0 and g[0] < g[1] < g[2] and L.radegs_geometry_bytes(1000, 1) > g[1]     # the coord map adds a 48-B record per Gaussian
+    assert 1_000_000 * 64 < g[2] < 1_000_000 * 400                                          # 64-B blend record + keys, indices, sort scratch
+    im = L.radegs_image_bytes(1920, 1080)
+    assert im >= 1920 * 1080 * 8 and L.radegs_image_bytes(960, 540) < im
+    b = [L.radegs_binning_bytes(r) for r in (0, 1000, 4_000_000)]
+    assert b[0] <= b[1] < b[2] and b[2] >= 4_000_000 * 16                                   # two key/value ping-pong pairs
