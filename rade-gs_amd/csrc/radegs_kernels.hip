@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(const PreFwdArgs a)
   preprocess_fwd<INTE>(mk3(m[0], m[1], m[2]), a.scales ? a.scales + 3 * (size_t)idx : nullptr,
                  a.rotations ? a.rotations + 4 * (size_t)idx : nullptr, a.cov3D_precomp ? a.cov3D_precomp + 6 * (size_t)idx : nullptr,
                  a.opacities[idx], a.D, a.shs ? a.shs + (size_t)idx * a.M * 3 : nullptr,
-                 a.colors_precomp ? a.colors_precomp + 3 * (size_t)idx : nullptr, cam, s, reinterpret_cast<float*>(a.eig + 3 * (size_t)idx));
+                 a.colors_precomp ? a.colors_precomp + 3 * (size_t)idx : nullptr, cam, s, a.eig ? reinterpret_cast<float*>(a.eig + 3 * (size_t)idx) : nullptr);
   a.radii[idx] = s.radius;
   a.tiles_touched[idx] = (uint32_t)s.tiles;
   a.rect[idx] = s.radius > 0 ? s.rect : 0u;

@@ -239,6 +239,9 @@ class _Resizable:
             weakref.finalize(self.tensor, _forget_image, holder)
 
         def _cb(_user, nbytes):
+            # every request stands for itself: the native side may retry with a smaller size after a failed one (alloc_image's
+            # fallback to the tile-wide formulation, rg_launch.inc), and a stale error must not outlive the retry that succeeded
+            self.error = None
             try:
                 self.tensor.resize_(int(nbytes))
                 if _POISON:
@@ -261,15 +264,21 @@ class _Resizable:
 
 def _zero_maps(channels, H, W, device):
     """All-zero maps for the outputs a call does not produce (the reference returns torch.full(0) maps whatever the flags,
-    rasterize_points.cu:71-77): FRESH memory every call, like the reference -- one zero-filled allocation cut into disjoint views,
-    so a caller editing one map in place touches neither the other maps nor any later call (one ~6 us fill at 1080p instead of five)."""
+    rasterize_points.cu:71-77): FRESH memory every call, like the reference -- ONE zero-filled allocation (one ~6 us fill at 1080p
+    instead of five) handed out as disjoint tensors that merely share its storage.  They are built with `set_`, not by slicing:
+    slices would be autograd VIEWS of one base, and an autograd Function that returns several views of one tensor makes every
+    later in-place edit of them raise ("Output N of ... is a view and is being modified inplace"); the reference's separate
+    torch.full tensors allow `depth[mask] = 0` / `normal *= x`, so these must too (tests/test_cabi.py)."""
     total = sum(channels)
     if total == 0:
         return []
-    flat = torch.zeros((total, H, W), dtype=torch.float32, device=device)
+    flat = torch.zeros(total * H * W, dtype=torch.float32, device=device)
+    storage = flat.untyped_storage()
     out, off = [], 0
     for c in channels:
-        out.append(flat[off:off + c])
+        t = torch.empty(0, dtype=torch.float32, device=device)
+        t.set_(storage, off * H * W, (c, H, W))     # own tensor, own version counter, no `_base`: not a view for autograd
+        out.append(t)
         off += c
     return out
 

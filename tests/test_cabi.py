@@ -158,3 +158,43 @@ def test_state_sizes_are_host_arithmetic():
     assert im >= 1920 * 1080 * 8 and L.radegs_image_bytes(960, 540) < im
     b = [L.radegs_binning_bytes(r) for r in (0, 1000, 4_000_000)]
     assert b[0] <= b[1] < b[2] and b[2] >= 4_000_000 * 16                                   # two key/value ping-pong pairs
+
+
+def test_unproduced_zero_maps_can_be_edited_in_place_under_autograd():
+    """the maps a call does not produce come from one zero-filled allocation; returned from an autograd Function as
+    slices they would be several views of one base, and `depth[mask] = 0` / `normal *= x` on them would raise.  The reference's
+    separate torch.full tensors allow it (rasterize_points.cu:71-77)."""
+    import diff_gaussian_rasterization._C as C
+
+    class F(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return (x * 2,) + tuple(C._zero_maps([3, 1, 3], 4, 5, x.device))
+
+        @staticmethod
+        def backward(ctx, *g):
+            return g[0] * 2
+
+    x = torch.ones(3, requires_grad=True)
+    y, a, b, c = F.apply(x)
+    assert a._base is None and b._base is None and c._base is None
+    a[0, 0, 0] = 5.0
+    b *= 3.0
+    c.add_(1.0)
+    assert float(a.sum()) == 5.0 and float(b.sum()) == 0.0 and float(c.sum()) == 60.0     # disjoint: no map sees another's edit
+    y.sum().backward()
+    assert torch.equal(x.grad, torch.full((3,), 2.0))
+    again = C._zero_maps([3, 1, 3], 4, 5, x.device)
+    assert all(float(t.abs().sum()) == 0.0 for t in again)                                 # fresh memory every call
+
+
+def test_failed_allocation_request_does_not_outlive_a_successful_retry():
+    """alloc_image (rg_launch.inc) retries without entry streams when the stream-sized request fails; the binding must not
+    raise the first request's stale exception after the retry succeeded."""
+    import diff_gaussian_rasterization._C as C
+    r = C._Resizable(torch.device("cpu"))
+    assert r.cb(None, 1 << 62) in (0, None)        # cannot be served: recorded, NULL returned to the native side
+    assert r.error is not None
+    p = r.cb(None, 4096)
+    assert p and r.error is None and r.tensor.numel() == 4096
+    r.release()
