@@ -248,6 +248,22 @@ def test_blend_paths_agree_with_oracle(coord, depth, streams, monkeypatch):
     check_backward(s, o, seed=62)
 
 
+@pytest.mark.parametrize("coord,depth", MODES)
+@pytest.mark.parametrize("merged,wn", [(1, 48), (1, 128), (0, 0)])
+def test_merged_stream_backward(coord, depth, merged, wn, monkeypatch):
+    """The stream backward exists with a per-tile LDS merge of the per-entry sums (blend_bwd_merged_kernel: windows of `wn` list
+    positions, one accumulator line per (tile, entry)) -- the default of the coord-map modes -- and without (one per (block, entry)) -- the
+    default of the others.  Both in every mode, lists several windows long, ragged image."""
+    monkeypatch.setenv("RADEGS_STREAMS", "1")
+    monkeypatch.setenv("RADEGS_BWD_MERGED", str(merged))
+    if wn:
+        monkeypatch.setenv("RADEGS_MERGE_WN", str(wn))
+    s = make_scene(5000, 203, 131, sh_degree=2, mu_px=5.0, seed=64, kernel_size=0.1, require_coord=coord, require_depth=depth, pose="random",
+                   bg=(0.3, 0.1, 0.7))
+    o, _ = check_forward(s)
+    check_backward(s, o, seed=64)
+
+
 def test_entry_streams_heavy_overdraw_termination_and_ragged_image(monkeypatch):
     """Forced entry streams on big splats: lists of hundreds of entries per block, rows of pixels that terminate early (their
     block stops consuming its list) next to rows that do not, partial rounds, tail tiles of a ragged image."""
