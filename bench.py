@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--flags", choices=("config", "both"), default="config",
                     help="'both': require_coord = require_depth = True whatever the config says -- the render.py mode "
                          "(gaussian_renderer/__init__.py:19,71-79: render() defaults), SURVEY.md 8(d)")
+    ap.add_argument("--mode", choices=("train", "forward"), default="train",
+                    help="'forward': the step is the forward alone under no_grad -- what the reference's inference callers execute "
+                         "(render.py:32, mesh_extract.py:56: render() with both maps on; use with --flags both); metric Mimages/s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-allreduce", action="store_true", help="run the RCCL gradient exchange even at world size 1 (path check)")
     ap.add_argument("--exchange", choices=("factored", "allreduce"), default="factored",
@@ -138,6 +141,7 @@ def main():
         C.set_grad_allocator(dev, bucket.allocator)
     counter = [0]
     last_state = []
+    STAGES4 = ("preprocess_fwd", "blend_fwd") if args.mode == "forward" else ("preprocess_fwd", "blend_fwd", "blend_bwd", "preprocess_bwd")
 
     def step():
         vm, pm, cp = cams[counter[0] % nviews]
@@ -148,6 +152,9 @@ def main():
                                    s.tanfovy, s.kernel_size, H, W, s.shs, s.sh_degree, cp, False, s.require_coord,
                                    s.require_depth, False)
         R, color, coord, mcoord, alpha, normal, depth, mdepth, radii, geom, binning, img = fw
+        last_state[:] = [R, geom, binning, img]
+        if args.mode == "forward":
+            return R, radii, None
         bw = C.rasterize_gaussians_backward(s.bg, s.means3D, radii, e, s.scales, s.rotations, 1.0, e, vm, pm,
                                             s.tanfovx, s.tanfovy, s.kernel_size, g["color"], g["coord"], g["mcoord"], g["depth"],
                                             g["mdepth"], g["alpha"], g["normal"], normal, s.shs, s.sh_degree, cp, geom, R,
@@ -178,7 +185,7 @@ def main():
     stages_warm = C.profile_collect()
     dom = None
     if args.warmup > 0:
-        dom = max(("preprocess_fwd", "blend_fwd", "blend_bwd", "preprocess_bwd"), key=lambda k: stages_warm[k][0] / max(stages_warm[k][1], 1))
+        dom = max(STAGES4, key=lambda k: stages_warm[k][0] / max(stages_warm[k][1], 1))
     # the dominant kernel is timed live on every 2nd step of the timed region (the event pair around it is a ~12 us stream bubble;
     # every 2nd step of a 9-view rotation still visits every view)
     C.profile_enable(True, only=dom, every=2 if (dom is not None and args.steps >= 8) else 1)   # no warm-up steps: every stage, in the timed region
@@ -196,7 +203,7 @@ def main():
     timed = C.profile_collect()
     if dom is None:
         stages = timed
-        dom = max(("preprocess_fwd", "blend_fwd", "blend_bwd", "preprocess_bwd"), key=lambda k: timed[k][0] / max(timed[k][1], 1))
+        dom = max(STAGES4, key=lambda k: timed[k][0] / max(timed[k][1], 1))
     else:
         stages = dict(stages_warm)
         stages[dom] = timed[dom]
@@ -216,7 +223,10 @@ def main():
         # per STEP, not per recorded interval: a stage may be timed in several pieces (block_lists: one kernel before the tile sort,
         # one after it)
         nrec = {k: v[1] for k, v in stages.items()}
-        per_step = max(nrec.get("preprocess_bwd", 0) if dom != "preprocess_bwd" else nrec.get("blend_bwd", 0), 1)
+        if args.mode == "forward":
+            per_step = max(nrec.get("preprocess_fwd", 0) if dom != "preprocess_fwd" else nrec.get("blend_fwd", 0), 1)
+        else:
+            per_step = max(nrec.get("preprocess_bwd", 0) if dom != "preprocess_bwd" else nrec.get("blend_bwd", 0), 1)
         ms = {k: (v[0] / (v[1] if k == dom else per_step) if v[1] else 0.0) for k, v in stages.items()}
         grouped = {"preprocess_fwd": ms["preprocess_fwd"],
                    "binning": ms["sort_depth"] + ms["scan"] + ms["emit_instances"] + ms["sort_tile"] + ms["tile_ranges"],
@@ -226,17 +236,26 @@ def main():
         gpu_ms = sum(grouped.values())
         kernel_name = {"blend_bwd": "blend_bwd_"}.get(dom, dom + "_")   # prefix of the kernel's name in the rocprof summaries
         tag = args.config if args.flags == "config" else args.config + "_both"
+        if args.mode == "forward":
+            tag += "_fwd"
+            for k in ("blend_bwd", "preprocess_bwd"):
+                ab["total"] -= ab[k]
+                ab[k] = 0
         traffic, traffic_note = pmc_traffic(kernel_name, tag, args.config, P, W, H)
         pairs = pair_evaluations(C, s, last_state, c)
         streams = pairs["formulation"].startswith("entry streams")
         bmoved = binning_bytes_moved(P, R, ((W + 15) // 16) * ((H + 15) // 16), streams)
         valu = valu_roofline(kernel_name, tag, args.config, P, W, H, dom_ms)
+        if args.mode == "forward":
+            metric, unit, value = f"forward-only Mimages/s, {args.config} (render.py / mesh_extract.py: render() under no_grad)", "Mimages/s", world / 1e6 / (elapsed / args.steps)
+        else:
+            metric, unit = ("fwd+bwd Msplats/s @1080p, 1M Gaussians; depth L1 vs ref" if args.config == "C2" else f"fwd+bwd Msplats/s, {args.config}"), "Msplats/s"
         out = {
-            "metric": ("fwd+bwd Msplats/s @1080p, 1M Gaussians; depth L1 vs ref" if args.config == "C2" else f"fwd+bwd Msplats/s, {args.config}")
-                      + (" [render.py mode: coord + depth maps]" if args.flags == "both" else ""), "value": round(value, 2), "unit": "Msplats/s",
+            "metric": metric + (" [render.py mode: coord + depth maps]" if args.flags == "both" else ""), "value": round(value, 6 if args.mode == "forward" else 2), "unit": unit,
+            "images_per_s": round(world / (elapsed / args.steps), 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH degree {s.sh_degree}, fwd+bwd one view per step per GPU, "
+            "config": {"workload": f"{args.config}: {P} Gaussians, {W}x{H}, SH degree {s.sh_degree}, {'forward only (no_grad)' if args.mode == 'forward' else 'fwd+bwd'} one view per step per GPU, "
                                    f"RGB{'+coord' if c else ''}{'+depth' if d else ''}{'+normal' if (c or d) else ''}",
                        "parallelism": f"view-parallel x{world}" + ((", RCCL all-reduce of 44 B + all-gather of 12 B/Gaussian/view (SH gradient factored)"
                                                                      if args.exchange == "factored" else ", RCCL all-reduce of 236 B/Gaussian grads")
@@ -288,7 +307,7 @@ def pair_evaluations(C, s, last_state, coord):
     reach = pad.view(pad.shape[0] // 16, 16, pad.shape[1] // 16, 16).amax(dim=(1, 3)).to(torch.int64)   # per tile: last entry any pixel blended
     tilewide = int(256 * reach.sum().item())
     env = os.environ.get("RADEGS_STREAMS")
-    streams = (not coord) and (R < 24 * P if env is None else env != "0")
+    streams = (R < 24 * P and (not coord or (R < 1024 * tiles and os.environ.get("RADEGS_STREAMS_COORD", "1") != "0"))) if env is None else env != "0"
     if streams:
         cons = C.debug_export("blk_consumed", torch.int32, 8 * tiles, P, R, W, H, coord, geom, binning, img).to(torch.int64)
         return {"formulation": "entry streams (8x4-pixel blocks)", "evaluated": int(32 * cons.sum().item()), "tilewide": tilewide}

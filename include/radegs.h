@@ -148,6 +148,16 @@ typedef struct RadegsBwdArgs {
 
 /* `accum_alloc` provides the per-Gaussian accumulation scratch (64 or 128 B per Gaussian). */
 int radegs_backward(const RadegsBwdArgs* args, radegs_alloc_fn accum_alloc, void* accum_user, void* stream);
+/* The SECOND half of radegs_backward on caller-supplied per-Gaussian sums (inspection / parity hook, like radegs_debug_export): the
+ * per-Gaussian backward (computeCov2DCUDA + preprocessCUDA backward, DGR/cuda_rasterizer/backward.cu:145-628) runs over `sums` instead
+ * of over what the blend backward accumulated.  sums: device [P][16] floats ([P][32] with require_coord) in the order
+ *   dL_dcolors[3], dL_dts, dL_dray_planes[2], dL_dnormals[3], dL_dmeans2D[3], dL_dconic.{x,y,w}, dL_dopacity (the render kernel's raw sum,
+ *   before backward.cu:395-403 rescales it), and with require_coord: dL_dview_points[3], dL_dcamera_planes[6], 7 unused
+ * holding the values the reference's render kernel leaves in those arrays (rasterizer_impl.cu:541-555).  What summation order does
+ * to the gradients is thereby taken out of a comparison: fed with the reference's own sums, every returned gradient must equal the
+ * reference's (tests/test_gpu_vs_compiled_reference.py).  Only geom_buffer, the inputs, the camera and the gradient outputs of `args`
+ * are read; nothing is allocated. */
+int radegs_backward_from_sums(const RadegsBwdArgs* args, const float* sums, void* stream);
 
 /* dL_dsh[P,M,3] = scale * sum_v basis(normalize(means3D - campos[v])) (x) drgb_clamped[v]   (rows beyond (D+1)^2 zero).
  * campos: [nviews,3], drgb_clamped: [nviews,P,3] -- the all-gathered per-view outputs of radegs_backward. */

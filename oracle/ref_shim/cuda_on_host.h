@@ -203,6 +203,11 @@ inline Cfg cfg(dim3 g, dim3 b) { return Cfg{g, b}; }
 template <class... P, class... A, size_t... I>
 inline void invoke(void (*k)(P...), const std::tuple<A...>& t, std::index_sequence<I...>) { k(std::get<I>(t)...); }
 
+// Called after every kernel launch has run to completion (launches are synchronous here): lets the driver of the reference's code
+// (ref_api.cpp) look at an array BETWEEN two kernels of one Rasterizer call -- the render kernel's raw opacity sums, which the
+// next kernel rescales in place (backward.cu:395-403).
+inline std::function<void()>& post_launch_hook() { static std::function<void()> h; return h; }
+
 }  // namespace cuda_on_host
 
 // kernel % cfg(grid, block)(args...)   ==   kernel<<<grid, block>>>(args...)
@@ -211,6 +216,7 @@ inline void operator%(void (*k)(P...), const cuda_on_host::Bound<A...>& b) {
   static_assert(sizeof...(P) == sizeof...(A), "kernel launched with the wrong number of arguments");
   std::function<void()> fn = [&]() { cuda_on_host::invoke(k, b.args, std::index_sequence_for<A...>{}); };
   cuda_on_host::run_grid(b.g, b.b, fn);
+  if (cuda_on_host::post_launch_hook()) cuda_on_host::post_launch_hook()();
 }
 
 // ---------------------------------------------------------------- cooperative groups

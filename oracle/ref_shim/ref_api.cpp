@@ -37,7 +37,7 @@ struct Ctx {
   std::vector<float> out_color, out_coord, out_mcoord, out_depth, out_mdepth, out_alpha, out_normal;
   std::vector<int> radii;
   std::vector<float> dL_dmeans3D, dL_dview_points, dL_dmeans2D, dL_dcolors, dL_dts, dL_dcamera_planes, dL_dray_planes, dL_dnormals, dL_dconic,
-      dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations;
+      dL_dopacity, dL_dopacity_raw, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations;
   std::vector<float> out9, accum_alpha, invraycov, out_alpha_integrated, out_color_integrated, out_coordinate2d, out_sdf;
   std::vector<unsigned char> condition;
 };
@@ -113,7 +113,13 @@ void ref_backward(void* h, const float* dL_dcolor, const float* dL_dcoord, const
   c->dL_dts.assign(P, 0.f); c->dL_dcamera_planes.assign(P * 6, 0.f); c->dL_dray_planes.assign(P * 2, 0.f); c->dL_dnormals.assign(P * 3, 0.f);
   c->dL_dconic.assign(P * 4, 0.f); c->dL_dopacity.assign(P, 0.f); c->dL_dcov3D.assign(P * 6, 0.f); c->dL_dsh.assign(P * c->M * 3, 0.f);
   c->dL_dscales.assign(P * 3, 0.f); c->dL_drotations.assign(P * 4, 0.f);
+  c->dL_dopacity_raw.assign(P, 0.f);
   if (P == 0) return;
+  // the first kernel of Rasterizer::backward is the render backward (rasterizer_impl.cu:500-541): what it leaves in dL_dopacity is
+  // the raw per-Gaussian sum; computeCov2DCUDA, two launches later, multiplies it by the opacity-compensation factor in place
+  int launches = 0;
+  cuda_on_host::post_launch_hook() = [&]() { if (launches++ == 0) c->dL_dopacity_raw = c->dL_dopacity; };
+  struct Unhook { ~Unhook() { cuda_on_host::post_launch_hook() = nullptr; } } unhook;
   CudaRasterizer::Rasterizer::backward(c->P, c->D, c->M, c->R, p(c->bg), c->W, c->H, p(c->means3D), p(c->shs), p(c->colors), c->out_alpha.data(),
                                        p(c->scales), c->scale_modifier, p(c->rots), p(c->cov3Dp), p(c->view), p(c->proj), p(c->campos), c->tanfovx,
                                        c->tanfovy, c->kernel_size, c->radii.data(), c->out_normal.data(), c->geom.data(), c->binning.data(),
@@ -205,7 +211,7 @@ long long ref_get(void* h, const char* name_c, void* dst, long long nbytes) {
     if (false) {}
     V(out_color); V(out_coord); V(out_mcoord); V(out_depth); V(out_mdepth); V(out_alpha); V(out_normal); V(radii);
     V(dL_dmeans3D); V(dL_dview_points); V(dL_dmeans2D); V(dL_dcolors); V(dL_dts); V(dL_dcamera_planes); V(dL_dray_planes); V(dL_dnormals);
-    V(dL_dconic); V(dL_dopacity); V(dL_dcov3D); V(dL_dsh); V(dL_dscales); V(dL_drotations);
+    V(dL_dconic); V(dL_dopacity); V(dL_dopacity_raw); V(dL_dcov3D); V(dL_dsh); V(dL_dscales); V(dL_drotations);
     V(out9); V(accum_alpha); V(invraycov); V(out_alpha_integrated); V(out_color_integrated); V(out_coordinate2d); V(out_sdf); V(condition);
 #undef V
     else return -1;

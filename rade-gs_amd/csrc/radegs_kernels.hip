@@ -67,7 +67,6 @@ struct PreFwdArgs {
   int* radii; float4* splat_a; float4* splat_b; uint32_t* tiles_touched; uint32_t* depth_key; uint8_t* clamped;
   float4* inte_rec;  // [P][2] {icr0..icr3 | icr4, icr5, well, 0}; INTE kernel only
   uint32_t* rect;    // [P] packed tile rectangle
-  float4* eig;       // [P][3] the solver's eigenvalues / eigenvectors, for the backward
 };
 
 template <bool INTE>
@@ -80,7 +79,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(const PreFwdArgs a)
   preprocess_fwd<INTE>(mk3(m[0], m[1], m[2]), a.scales ? a.scales + 3 * (size_t)idx : nullptr,
                  a.rotations ? a.rotations + 4 * (size_t)idx : nullptr, a.cov3D_precomp ? a.cov3D_precomp + 6 * (size_t)idx : nullptr,
                  a.opacities[idx], a.D, a.shs ? a.shs + (size_t)idx * a.M * 3 : nullptr,
-                 a.colors_precomp ? a.colors_precomp + 3 * (size_t)idx : nullptr, cam, s, a.eig ? reinterpret_cast<float*>(a.eig + 3 * (size_t)idx) : nullptr);
+                 a.colors_precomp ? a.colors_precomp + 3 * (size_t)idx : nullptr, cam, s);
   a.radii[idx] = s.radius;
   a.tiles_touched[idx] = (uint32_t)s.tiles;
   a.rect[idx] = s.radius > 0 ? s.rect : 0u;
@@ -98,7 +97,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(const PreFwdArgs a)
       rb[1] = make_float4(s.cp[4], s.cp[5], s.vp[0], s.vp[1]);
       rb[2] = make_float4(s.vp[2], 0.f, 0.f, 0.f);
     }
-    a.clamped[idx] = (uint8_t)(s.clamped | (s.eigD != 0 ? 8u : 0u));   // bits 0..2: SH clamp flags; bit 3: eigen-solver converged
+    a.clamped[idx] = (uint8_t)s.clamped;   // bits 0..2: SH clamp flags
     if constexpr (INTE) {
       float4* ri = a.inte_rec + 2 * (size_t)idx;
       ri[0] = make_float4(s.icr[0], s.icr[1], s.icr[2], s.icr[3]);
@@ -1432,13 +1431,13 @@ struct PreBwdArgs {
   int P, D, M;
   const float* means3D; const float* scales; const float* rotations; const float* cov3D_precomp; const float* shs;
   const int* radii; const float4* splat_a; const uint8_t* clamped; const float* acc; int rec;
-  const float4* eig;   // [P][3] the forward's eigen-decomposition (GeomState::eig), or null: re-run the solver
   CamArgs cam;
   float* dL_dmean2D; float* dL_dcolor; float* dL_dopacity; float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale;
   float* dL_drot;
   float* dL_drgb_clamped;  // optional [P,3]: dL/dRGB with the clamp mask applied (the view-parallel factored exchange)
   int opacity_grad_intended;  // RadegsBwdArgs::opacity_grad_intended (include/radegs.h)
   int drgb_done;              // dL_drgb_clamped was already written by drgb_clamped_kernel (RadegsBwdArgs::drgb_ready)
+  int acc_final;              // the records hold the reference's FINAL per-Gaussian sums (constant factors applied): radegs_backward_from_sums
 };
 
 // dL/dRGB with the SH clamp mask applied, straight from the blend backward's sums (the first three floats of every accumulator
@@ -1526,7 +1525,7 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
       }
       // constant factors the blend backward left out of its sums (linear, so they commute with the sum):
       // 1/focal on the plane gradients (backward.cu:917-922,939-940), W/2 and H/2 on mean2D (:1002-1003)
-      {
+      if (!a.acc_final) {
         const float ifx = 1.0f / cam.focal_x, ify = 1.0f / cam.focal_y;
         acc.drp[0] *= ifx; acc.drp[1] *= ify;
 #pragma unroll
@@ -1557,16 +1556,9 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
       }
       SplatBwd o;
       o.dscale[0] = o.dscale[1] = o.dscale[2] = 0; o.drot[0] = o.drot[1] = o.drot[2] = o.drot[3] = 0;
-      const unsigned cflags = (unsigned)a.clamped[idx];   // bits 0..2: SH clamp flags; bit 3: the forward's eigen-solver converged
-      float eigc[12];
-      if (a.eig) {
-        const float4* re = a.eig + 3 * i;
-        const float4 e0 = re[0], e1 = re[1], e2 = re[2];
-        eigc[0] = e0.x; eigc[1] = e0.y; eigc[2] = e0.z; eigc[3] = e0.w; eigc[4] = e1.x; eigc[5] = e1.y; eigc[6] = e1.z; eigc[7] = e1.w;
-        eigc[8] = e2.x; eigc[9] = e2.y; eigc[10] = e2.z; eigc[11] = e2.w;
-      }
+      const unsigned cflags = (unsigned)a.clamped[idx];   // bits 0..2: SH clamp flags
       preprocess_bwd(mk3(m[0], m[1], m[2]), has_sr ? sc3 : nullptr, has_sr ? rq4 : nullptr, cov, op_combined, a.D, row,
-                     cflags & 7u, cam, acc, row, o, a.eig ? eigc : nullptr, (cflags & 8u) ? 3 : 0);
+                     cflags & 7u, cam, acc, row, o);
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         a.dL_dmean2D[3 * i + c] = acc.dmean2D[c];

@@ -12,7 +12,6 @@
 //   * splat_b  [P][12] f32 (48 B), only when the coord map is requested:
 //                 { cp0..cp3 | cp4, cp5, vpx, vpy | vpz, 0, 0, 0 }
 //   * depth_key/tiles_touched/clamped: per-Gaussian scalars for binning and the backward
-//   * eig      [P][12] f32: the forward's eigen-decomposition of the 3D covariance, reused by the backward
 //   * the reference's cov3D array is not stored at all: the backward re-derives it from
 //     scale/rotation with the same code (bit-identical), saving 48 B/Gaussian of traffic.
 //
@@ -49,9 +48,6 @@ struct GeomState {
   uint32_t* depth_key;     // [P]
   uint8_t* clamped;        // [P]
   uint32_t* rect;          // [P] packed tile rectangle (x0 | y0<<8 | w<<16 | h<<24): all instance emission needs per Gaussian
-  float* eig;              // [P*12] eigen-decomposition of the 3D covariance as the forward's solver left it (3 values, 9 vector
-                           // entries; the solver's status rides in bit 3 of `clamped`): the backward reuses it instead of re-running
-                           // the iterative solver (the reference recomputes, backward.cu:221-223 -- same bits either way)
   // forward-only scratch
   uint32_t* depth_key_sorted;  // [P]
   uint32_t* idx_sorted;        // [P]
@@ -69,7 +65,6 @@ struct GeomState {
     g.depth_key = c.take<uint32_t>(P);
     g.clamped = c.take<uint8_t>(P);
     g.rect = c.take<uint32_t>(P);
-    g.eig = c.take<float>(P * 12);
     g.depth_key_sorted = c.take<uint32_t>(P);
     g.idx_sorted = c.take<uint32_t>(P);
     g.offsets = c.take<uint32_t>(P);

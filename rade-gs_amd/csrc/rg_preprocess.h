@@ -82,9 +82,7 @@ struct Cov2D {
   v3 uvh, uvh_m, uvh_mn;
 };
 
-// cached != nullptr: the forward's eigen-decomposition of this covariance ({d0,d1,d2, a0..a8}) and the solver's status; the
-// iterative solver is deterministic, so reusing its output gives the same bits as re-running it
-RG_HD void cov2d_common(v3 mean, const Camera& cam, const float cov3D[6], Cov2D& o, const float* cached = nullptr, int cached_D = 0) {
+RG_HD void cov2d_common(v3 mean, const Camera& cam, const float cov3D[6], Cov2D& o) {
   v3 t = xform43(mean, cam.view);
   const float limx = 1.3f * cam.tan_fovx, limy = 1.3f * cam.tan_fovy;
   float txtz = t.x / t.z, tytz = t.y / t.z;
@@ -108,15 +106,7 @@ RG_HD void cov2d_common(v3 mean, const Camera& cam, const float cov3D[6], Cov2D&
   o.det1 = (float)fmax(1e-6, (double)((c00 + ks) * (c11 + ks) - c01 * c01));
   o.coef = (float)sqrt((double)o.det0 / ((double)o.det1 + 1e-6) + 1e-6);
 
-  if (cached) {
-#pragma unroll
-    for (int i = 0; i < 3; i++) o.eig.d[i] = cached[i];
-#pragma unroll
-    for (int i = 0; i < 9; i++) o.eig.a[i] = cached[3 + i];
-    o.D = cached_D;
-  } else {
-    o.D = sym_eigen3(o.Vrk.c[0][0], o.Vrk.c[1][0], o.Vrk.c[2][0], o.Vrk.c[1][1], o.Vrk.c[2][1], o.Vrk.c[2][2], o.eig);
-  }
+  o.D = sym_eigen3(o.Vrk.c[0][0], o.Vrk.c[1][0], o.Vrk.c[2][0], o.Vrk.c[1][1], o.Vrk.c[2][1], o.Vrk.c[2][2], o.eig);
   const float e0 = o.eig.d[0], e1 = o.eig.d[1], e2 = o.eig.d[2];
   o.min_id = e0 > e1 ? (e1 > e2 ? 2 : 1) : (e0 > e2 ? 2 : 0);
   const float emin = o.min_id == 0 ? e0 : (o.min_id == 1 ? e1 : e2);
@@ -155,7 +145,6 @@ struct SplatFwd {
   // 3D covariance was well conditioned (computeCov2D<true>, forward.cu:187-235)
   float icr[6];
   bool well;
-  int eigD;             // status of the eigen-solver (its output goes straight to memory: preprocess_fwd's eig_out)
 };
 
 // SH -> RGB (+0.5, clamp at 0, remember which channels clamped).  sh points at this
@@ -193,10 +182,8 @@ RG_HD void sh_to_rgb(int deg, const float* sh, v3 pos, const float campos[3], fl
 // One Gaussian.  cov3D_in: precomputed covariance (6) or nullptr; scale/quat used otherwise.
 // sh: this Gaussian's SH block or nullptr; color_in: precomputed RGB (3) or nullptr.
 template <bool INTE = false>
-// eig_out: 12 floats receiving the solver's {d0,d1,d2, a0..a8} for the backward (written as soon as they exist, for every Gaussian
-// that passes the near plane: keeping them in registers until visibility is known cost the forward kernel 30 % -- 87 -> 114 us)
 RG_HD void preprocess_fwd(v3 p_orig, const float* scale3, const float* quat4, const float* cov3D_in, float opacity,
-                          int deg, const float* sh, const float* color_in, const Camera& cam, SplatFwd& o, float* eig_out = nullptr) {
+                          int deg, const float* sh, const float* color_in, const Camera& cam, SplatFwd& o) {
   o.radius = 0;
   o.tiles = 0;
   o.clamped = 0;
@@ -220,18 +207,6 @@ RG_HD void preprocess_fwd(v3 p_orig, const float* scale3, const float* quat4, co
 
   Cov2D g;
   cov2d_common(p_orig, cam, cov3D, g);
-  if (eig_out) {
-#if defined(__HIP_DEVICE_COMPILE__)   // three 16-byte stores (the build runs without the SLP vectoriser, which would have formed them)
-    float4* e4 = reinterpret_cast<float4*>(eig_out);
-    e4[0] = make_float4(g.eig.d[0], g.eig.d[1], g.eig.d[2], g.eig.a[0]);
-    e4[1] = make_float4(g.eig.a[1], g.eig.a[2], g.eig.a[3], g.eig.a[4]);
-    e4[2] = make_float4(g.eig.a[5], g.eig.a[6], g.eig.a[7], g.eig.a[8]);
-#else
-    for (int i = 0; i < 3; i++) eig_out[i] = g.eig.d[i];
-    for (int i = 0; i < 9; i++) eig_out[3 + i] = g.eig.a[i];
-#endif
-  }
-  o.eigD = g.D;
   const float ks = cam.kernel_size;
   const float cvx = g.cov.c[0][0] + ks, cvy = g.cov.c[0][1], cvz = g.cov.c[1][1] + ks;
   float coef = g.coef;

@@ -166,10 +166,9 @@ RG_HD void cov3d_bwd(const float s3[3], float mod, const float q[4], const float
 // op_combined: what the reference's kernel reads as `conic_opacity[idx].w` -- by default the conic gradient a.dconic[2] (upstream's
 // argument slip, include/radegs.h::opacity_grad_intended), else opacity*coef as stored by the forward.  sh/dsh may be null (precomputed colours).
 RG_HD void preprocess_bwd(v3 mean, const float* scale3, const float* quat4, const float cov3D[6], float op_combined, int deg,
-                          const float* sh, unsigned clamped, const Camera& cam, const SplatAcc& a, float* dsh, SplatBwd& o,
-                          const float* eig_cached = nullptr, int eig_D = 0) {
+                          const float* sh, unsigned clamped, const Camera& cam, const SplatAcc& a, float* dsh, SplatBwd& o) {
   Cov2D g;
-  cov2d_common(mean, cam, cov3D, g, eig_cached, eig_D);
+  cov2d_common(mean, cam, cov3D, g);
   const v3 t = g.t;
   const float txtz = g.txtz, tytz = g.tytz;
   const float h_x = cam.focal_x, h_y = cam.focal_y, ks = cam.kernel_size;

@@ -76,7 +76,7 @@ class RadegsIntegrateArgs(ctypes.Structure):
 
 
 # every symbol include/radegs.h declares
-EXPORTED_SYMBOLS = ("radegs_forward", "radegs_backward", "radegs_mark_visible", "radegs_integrate", "radegs_sh_grad_from_views", "radegs_geometry_bytes", "radegs_image_bytes",
+EXPORTED_SYMBOLS = ("radegs_forward", "radegs_backward", "radegs_backward_from_sums", "radegs_mark_visible", "radegs_integrate", "radegs_sh_grad_from_views", "radegs_geometry_bytes", "radegs_image_bytes",
                     "radegs_binning_bytes", "radegs_debug_export", "radegs_forget_image", "radegs_last_error", "radegs_version", "radegs_profile_enable",
                     "radegs_profile_select", "radegs_profile_stride", "radegs_binning_stats", "radegs_profile_num_stages", "radegs_profile_stage_name", "radegs_profile_collect",
                     # fused pre/post steps (bound in graphics_utils.py / gaussian_model_ops.py)
@@ -147,6 +147,8 @@ def library():
                                      ctypes.c_void_p, ctypes.c_void_p]
         L.radegs_backward.restype = ctypes.c_int
         L.radegs_backward.argtypes = [ctypes.POINTER(RadegsBwdArgs), _ALLOC_FN, ctypes.c_void_p, ctypes.c_void_p]
+        L.radegs_backward_from_sums.restype = ctypes.c_int
+        L.radegs_backward_from_sums.argtypes = [ctypes.POINTER(RadegsBwdArgs), ctypes.c_void_p, ctypes.c_void_p]
         L.radegs_integrate.restype = ctypes.c_int
         L.radegs_integrate.argtypes = [ctypes.POINTER(RadegsIntegrateArgs)] + [_ALLOC_FN, ctypes.c_void_p] * 4 + [ctypes.c_void_p]
         L.radegs_sh_grad_from_views.restype = ctypes.c_int
@@ -416,6 +418,42 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             dL_dscales.zero_()
             dL_drotations.zero_()
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def backward_from_sums(sums, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx,
+                       tan_fovy, kernel_size, image_height, image_width, sh, degree, campos, geomBuffer, require_coord):
+    """Test hook (radegs_backward_from_sums, include/radegs.h): the per-Gaussian half of the backward over caller-supplied per-Gaussian
+    sums [P, 16 | 32] (the reference's render-kernel sums, its constant factors included).  Returns the 8-tuple of
+    rasterize_gaussians_backward."""
+    _require_gpu(means3D, "means3D")
+    L = library()
+    dev = means3D.device
+    P = int(means3D.size(0))
+    M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
+    fo = dict(dtype=torch.float32, device=dev)
+    rec = 32 if require_coord else 16
+    sm = _f32(sums, "sums")
+    if tuple(sm.shape) != (P, rec):
+        raise RuntimeError(f"sums must be ({P}, {rec})")
+    out = [torch.full(s, float("nan"), **fo) for s in ((P, 3), (P, 3), (P, 1), (P, 3), (P, 6), (P, max(M, 1), 3), (P, 3), (P, 4))]
+    dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = out
+    m3, col = _f32(means3D, "means3D"), _f32(colors, "colors_precomp")
+    sc, rot, cov = _f32(scales, "scales"), _f32(rotations, "rotations"), _f32(cov3D_precomp, "cov3D_precomp")
+    vm, pm, cp, shs = _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix"), _f32(campos, "campos"), _f32(sh, "shs")
+    rad, gb = radii.contiguous(), geomBuffer.contiguous()
+    a = RadegsBwdArgs(P, int(degree), M, 0, int(image_width), int(image_height), None, _ptr(m3), _ptr(shs), _ptr(col), None, _ptr(sc), _ptr(rot),
+                      _ptr(cov), _ptr(vm), _ptr(pm), _ptr(cp), float(scale_modifier), float(tan_fovx), float(tan_fovy), float(kernel_size),
+                      _ptr(rad), None, _ptr(gb), None, None, None, None, None, None, None, None, None,
+                      _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
+                      _ptr(dL_dsh) if M else None, _ptr(dL_dscales), _ptr(dL_drotations), int(bool(require_coord)), 0, 0, None,
+                      int(bool(OPACITY_GRAD_INTENDED)), None, None)
+    with torch.cuda.device(dev):
+        rc = L.radegs_backward_from_sums(ctypes.byref(a), _ptr(sm), _stream(dev))
+    _check(rc, "radegs_backward_from_sums")
+    if sc is None:
+        dL_dscales.zero_()
+        dL_drotations.zero_()
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, (dL_dsh if M else None), dL_dscales, dL_drotations
 
 
 def sh_grad_from_views(means3D, campos_all, drgb_all, degree, M, scale=1.0, out=None):

@@ -78,3 +78,53 @@ class HipRun:
 
 def outputs_numpy(out):
     return [o.detach().cpu().numpy() for o in out]
+
+
+# ---- the per-Gaussian sums between the two halves of the backward (DESIGN.md 7.6) -------------------------------------------------
+def reference_sums(get, P, coord, raw_opacity="dL_dopacity_raw"):
+    """[P, 16 | 32] float32 record of the render kernel's per-Gaussian sums in the order radegs_backward_from_sums takes them
+    (include/radegs.h), from a checker's arrays: `get` = Ref.get (compiled reference; raw_opacity 'dL_dopacity_raw') or Oracle.get
+    (raw_opacity 'acc_dopacity')."""
+    rec = np.zeros((P, 32 if coord else 16), np.float32)
+    rec[:, 0:3] = get("dL_dcolors").reshape(P, 3)
+    rec[:, 3] = get("dL_dts").reshape(P)
+    rec[:, 4:6] = get("dL_dray_planes").reshape(P, 2)
+    rec[:, 6:9] = get("dL_dnormals").reshape(P, 3)
+    rec[:, 9:12] = get("dL_dmeans2D").reshape(P, 3)
+    dc = get("dL_dconic").reshape(P, 4)
+    rec[:, 12], rec[:, 13], rec[:, 14] = dc[:, 0], dc[:, 1], dc[:, 3]
+    rec[:, 15] = get(raw_opacity).reshape(P)
+    if coord:
+        rec[:, 16:19] = get("dL_dview_points").reshape(P, 3)
+        rec[:, 19:25] = get("dL_dcamera_planes").reshape(P, 6)
+    return rec
+
+
+def hip_sums_as_reference(acc, s):
+    """The blend backward's accumulator records (_C.LAST_ACC, [P, 16 | 32]) with the constant factors it leaves to the per-Gaussian
+    kernel applied in float64 (1/focal on the plane sums, W/2 and H/2 on mean2D: backward.cu:917-922, 939-940, 1002-1003), i.e. in the
+    reference's units, for comparison with reference_sums()."""
+    a = acc.detach().cpu().numpy().astype(np.float64).reshape(s.means3D.shape[0], -1).copy()
+    fx, fy = s.W / (2.0 * s.tanfovx), s.H / (2.0 * s.tanfovy)
+    a[:, 4] /= np.float32(fx); a[:, 5] /= np.float32(fy)
+    a[:, 9] *= 0.5 * s.W; a[:, 10] *= 0.5 * s.H
+    if a.shape[1] == 32:
+        a[:, 19:25:2] /= np.float32(fx); a[:, 20:25:2] /= np.float32(fy)
+    return a
+
+
+def backward_from_sums(h, sums):
+    """HipRun `h` after forward_native(): the per-Gaussian half of the backward over `sums` (numpy [P, rec]) -> dict of numpy gradients."""
+    import torch
+    C, rs = h.C, h.rs
+    e = torch.Tensor([])
+    st = h.state
+    out = C.backward_from_sums(torch.from_numpy(np.ascontiguousarray(sums, dtype=np.float32)).to(h.dev), h.means3D.detach(), st[8],
+                               e if h.colors is None else h.colors.detach(), e if h.scales is None else h.scales.detach(),
+                               e if h.rotations is None else h.rotations.detach(), rs.scale_modifier,
+                               e if h.cov3D is None else h.cov3D.detach(), rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
+                               rs.kernel_size, rs.image_height, rs.image_width, e if h.shs is None else h.shs.detach(), rs.sh_degree,
+                               rs.campos, st[9], rs.require_coord)
+    torch.cuda.synchronize(h.dev)
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
+    return {k: (None if t is None else t.cpu().numpy()) for k, t in zip(names, out)}

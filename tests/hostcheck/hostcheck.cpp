@@ -27,15 +27,14 @@ extern "C" {
 void hc_preprocess_fwd(int P, int deg, int M, const float* means, const float* scales, const float* rots, const float* cov3D,
                        const float* opac, const float* shs, const float* colors, const float* view, const float* proj,
                        const float* campos, int W, int H, float tanfovx, float tanfovy, float kernel_size, float scale_modifier,
-                       float* out_f, int* out_i, float* out_eig, int* out_eigD) {
+                       float* out_f, int* out_i) {
   Camera cam = make_cam(view, proj, campos, W, H, tanfovx, tanfovy, kernel_size, scale_modifier);
   for (int i = 0; i < P; i++) {
     SplatFwd s;
     memset(&s, 0, sizeof(s));
     preprocess_fwd(mk3(means[3 * i], means[3 * i + 1], means[3 * i + 2]), scales ? scales + 3 * i : nullptr, rots ? rots + 4 * i : nullptr,
                    cov3D ? cov3D + 6 * i : nullptr, opac[i], deg, shs ? shs + (size_t)i * M * 3 : nullptr,
-                   colors ? colors + 3 * i : nullptr, cam, s, out_eig ? out_eig + 12 * (size_t)i : nullptr);
-    if (out_eigD) out_eigD[i] = s.eigD;   // the solver's output as the forward kernel stores it for the backward (GeomState::eig)
+                   colors ? colors + 3 * i : nullptr, cam, s);
     float* f = out_f + (size_t)i * 27;
     f[0] = s.mx; f[1] = s.my; f[2] = s.cx; f[3] = s.cy; f[4] = s.cz; f[5] = s.op; f[6] = s.ts;
     for (int k = 0; k < 3; k++) f[7 + k] = s.rgb[k];
@@ -70,7 +69,7 @@ void hc_preprocess_inte(int P, int deg, int M, const float* means, const float* 
 void hc_preprocess_bwd(int P, int deg, int M, const float* means, const float* scales, const float* rots, const float* cov3D_pre,
                        const float* shs, const int* radii, const int* clamped, const float* op_combined, const float* view,
                        const float* proj, const float* campos, int W, int H, float tanfovx, float tanfovy, float kernel_size,
-                       float scale_modifier, const float* acc, float* out, float* dsh, const float* eig, const int* eigD) {
+                       float scale_modifier, const float* acc, float* out, float* dsh) {
   Camera cam = make_cam(view, proj, campos, W, H, tanfovx, tanfovy, kernel_size, scale_modifier);
   for (int i = 0; i < P; i++) {
     float* o = out + (size_t)i * 17;
@@ -85,7 +84,7 @@ void hc_preprocess_bwd(int P, int deg, int M, const float* means, const float* s
     memset(&b, 0, sizeof(b));
     preprocess_bwd(mk3(means[3 * i], means[3 * i + 1], means[3 * i + 2]), scales ? scales + 3 * i : nullptr, rots ? rots + 4 * i : nullptr,
                    cov, op_combined[i], deg, shs ? shs + (size_t)i * M * 3 : nullptr, (unsigned)clamped[i], cam, a,
-                   dsh ? dsh + (size_t)i * M * 3 : nullptr, b, eig ? eig + 12 * (size_t)i : nullptr, eig ? eigD[i] : 0);
+                   dsh ? dsh + (size_t)i * M * 3 : nullptr, b);
     for (int k = 0; k < 3; k++) o[k] = b.dmean3D[k];
     o[3] = b.dopacity;
     for (int k = 0; k < 6; k++) o[4 + k] = b.dcov3D[k];

@@ -41,7 +41,7 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
-def preprocess_fwd(scene, colors=None, cov3D=None, use_sh=True, with_eig=False):
+def preprocess_fwd(scene, colors=None, cov3D=None, use_sh=True):
     s = scene
     P = s.means3D.shape[0]
     means, scales, rots, opac = _f(s.means3D), _f(s.scales), _f(s.rotations), _f(s.opacities)
@@ -53,14 +53,12 @@ def preprocess_fwd(scene, colors=None, cov3D=None, use_sh=True, with_eig=False):
         scales = rots = None
     out_f = np.zeros((P, 27), np.float32)
     out_i = np.zeros((P, 3), np.int32)
-    eig = np.zeros((P, 12), np.float32) if with_eig else None
-    eigD = np.zeros(P, np.int32) if with_eig else None
     L = lib()
     L.hc_preprocess_fwd(ctypes.c_int(P), ctypes.c_int(s.sh_degree), ctypes.c_int(M), _p(means), _p(scales), _p(rots), _p(cov3D),
                         _p(opac), _p(shs), _p(colors), _p(_f(s.viewmatrix)), _p(_f(s.projmatrix)), _p(_f(s.campos)),
                         ctypes.c_int(s.W), ctypes.c_int(s.H), ctypes.c_float(s.tanfovx), ctypes.c_float(s.tanfovy),
-                        ctypes.c_float(s.kernel_size), ctypes.c_float(1.0), _p(out_f), _p(out_i), _p(eig), _p(eigD))
-    return (out_f, out_i, eig, eigD) if with_eig else (out_f, out_i)
+                        ctypes.c_float(s.kernel_size), ctypes.c_float(1.0), _p(out_f), _p(out_i))
+    return out_f, out_i
 
 
 def preprocess_inte(scene):
@@ -76,7 +74,7 @@ def preprocess_inte(scene):
     return out_f, out_i
 
 
-def preprocess_bwd(scene, radii, clamped, op_combined, acc, use_sh=True, cov3D=None, eig=None, eigD=None):
+def preprocess_bwd(scene, radii, clamped, op_combined, acc, use_sh=True, cov3D=None):
     s = scene
     P = s.means3D.shape[0]
     means, scales, rots = _f(s.means3D), _f(s.scales), _f(s.rotations)
@@ -94,8 +92,7 @@ def preprocess_bwd(scene, radii, clamped, op_combined, acc, use_sh=True, cov3D=N
                         _p(shs), _p(radii), _p(clamped), _p(_f(op_combined)), _p(_f(s.viewmatrix)), _p(_f(s.projmatrix)),
                         _p(_f(s.campos)), ctypes.c_int(s.W), ctypes.c_int(s.H), ctypes.c_float(s.tanfovx),
                         ctypes.c_float(s.tanfovy), ctypes.c_float(s.kernel_size), ctypes.c_float(1.0), _p(_f(acc)), _p(out),
-                        _p(dsh) if shs is not None else None, _p(None if eig is None else _f(eig)),
-                        _p(None if eigD is None else np.ascontiguousarray(eigD, dtype=np.int32)))
+                        _p(dsh) if shs is not None else None)
     return out, dsh
 
 

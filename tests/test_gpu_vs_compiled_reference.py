@@ -65,24 +65,45 @@ def test_hip_equals_the_references_own_code(coord, depth, ks, full):
             scale = float(np.abs(b).max()) + 1e-30
             assert frac_close(got[k], b) > 0.99, (k, frac_close(got[k], b))
             assert close(got[k], b, atol=ATOL + 1e-4 * scale, rtol=1e-3).all(), (k, float(np.abs(got[k] - b).max()), scale)
+        # ---- the three geometry gradients of the EXECUTED backward, without summation order in the way.  The slip
+        # term (rasterizer_impl.cu:568) multiplies a cancellation residue by an accumulated sum, so the reference's own values move by
+        # 1e-4..1e-3 of their scale when its float atomics land in another order: no element-wise statement about the end-to-end
+        # values can be strict.  The backward is two halves, and each half can be:
+        #   (1) the per-Gaussian half (computeCov2DCUDA + preprocessCUDA bwd) fed with the REFERENCE'S OWN nine per-Gaussian sums
+        #       (radegs_backward_from_sums) must return the reference's gradients element-wise at 1e-5 / 1e-4 -- executed mode, every tensor;
+        #   (2) the blend half's sums against the reference's sums inside the fp32 band of such sums (>= 99 % strict, the rest within
+        #       1e-4 of the tensor's scale / 1e-3 relative), like the three tensors above, which ARE such sums.
+        from gpu_util import backward_from_sums, hip_sums_as_reference, reference_sums
+        P = s.means3D.shape[0]
+        want_sums = reference_sums(r.get, P, s.require_coord)
+        got2 = backward_from_sums(h, want_sums)
+        for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
+            b = want_g[k].reshape(got2[k].shape)
+            bad = ~close(got2[k], b)
+            assert not bad.any(), (f"{k} from the reference's sums: {int(bad.sum())} of {bad.size} elements outside 1e-5/1e-4, "
+                                   f"max |diff| {float(np.abs(got2[k] - b).max()):.3e}, scale {float(np.abs(b).max()):.3e}")
+        import diff_gaussian_rasterization._C as C
+        C.KEEP_ACC = True
+        try:
+            h3 = HipRun(s, "cuda:0")
+            h3.forward()
+            got3 = h3.backward(g)
+            mine = hip_sums_as_reference(C.LAST_ACC, s)
+        finally:
+            C.KEEP_ACC = False
+            C.LAST_ACC = None
+        vis = r.get("radii") > 0
+        cols = {"dL_dcolors": slice(0, 3), "dL_dts": slice(3, 4), "dL_dray_planes": slice(4, 6), "dL_dnormals": slice(6, 9),
+                "dL_dmeans2D": slice(9, 12), "dL_dconic": slice(12, 15), "dL_dopacity_raw": slice(15, 16)}
+        if s.require_coord:
+            cols.update({"dL_dview_points": slice(16, 19), "dL_dcamera_planes": slice(19, 25)})
+        for k, sl in cols.items():
+            a_, b_ = mine[vis][:, sl], want_sums[vis][:, sl].astype(np.float64)
+            scale = float(np.abs(b_).max()) + 1e-30
+            assert frac_close(a_, b_) > 0.99, (k, frac_close(a_, b_))
+            assert close(a_, b_, atol=ATOL + 1e-4 * scale, rtol=1e-3).all(), (k, float(np.abs(a_ - b_).max()), scale)
         for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations"):
-            b = want_g[k].reshape(got[k].shape)
-            scale = float(np.abs(b).max()) + 1e-30
-            assert frac_close(got[k], b) > 0.97, (k, frac_close(got[k], b))
-            # at kernel_size 0 the slip term is a cancellation residue scaled by an accumulated sum: the reference's own value moves by
-            # up to ~1e-3 of the scale with the order of its atomics, with a heavy tail over a million Gaussians and C5's long sums
-            # (the same build, same inputs: largest single difference 3e-2 of the scale in one run, 6e-2 in the next -- our atomics land
-            # in a different order every run).  A bound on the single worst element is therefore not a property of either
-            # implementation; the distribution is: all but 1e-4 of the elements inside 3e-3 of the scale, and the rms of the
-            # difference (which a handful of outliers of the size of the scale itself would already break) inside 3e-3 as well.
-            # The strict element-wise check of these three tensors at full size runs on the intended derivative (test_gpu_full.py).
-            assert np.isfinite(got[k]).all(), k
-            d = np.abs(got[k].astype(np.float64) - b)
-            inside = d <= ATOL + 3e-3 * scale + 1e-3 * np.abs(b)
-            rms = float(np.sqrt(np.mean(d * d)))
-            print(f"{k}: executed-mode difference / scale: rms {rms / scale:.2e}, max {float(d.max()) / scale:.2e}, outside the band {1.0 - float(inside.mean()):.2e}")
-            assert inside.mean() >= 1.0 - 1e-4, (k, float(inside.mean()), float(d.max()), scale)
-            assert rms <= 3e-3 * scale, (k, rms, float(d.max()), scale)
+            assert np.isfinite(got[k]).all() and np.isfinite(got3[k]).all(), k
     finally:
         ref.set_exp("libm")
         ref.set_num_threads(1)

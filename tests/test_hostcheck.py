@@ -44,7 +44,7 @@ def test_preprocess_forward_and_backward_bit_exact(case):
     P = s.means3D.shape[0]
     o = oracle_for(s)
     o.forward()
-    f, i, eig, eigD = hc.preprocess_fwd(s, with_eig=True)
+    f, i = hc.preprocess_fwd(s)
     radii = o.get("radii")
     vis = radii > 0
     assert vis.sum() > P // 2
@@ -78,17 +78,15 @@ def test_preprocess_forward_and_backward_bit_exact(case):
         finally:
             orc.set_opacity_slip(1)
         _check_bwd(s, o, gr, radii, clb, co, P, intended)
-        # the backward fed with the forward's eigen-decomposition (what the kernels do, GeomState::eig) instead of re-running the solver
-        _check_bwd(s, o, gr, radii, clb, co, P, intended, eig=eig, eigD=eigD)
 
 
-def _check_bwd(s, o, gr, radii, clb, co, P, intended, eig=None, eigD=None):
+def _check_bwd(s, o, gr, radii, clb, co, P, intended):
     acc = np.zeros((P, 25), np.float32)
     acc[:, 0:3] = o.get("acc_dcolors", (P, 3)); acc[:, 3] = o.get("dL_dts"); acc[:, 4:6] = o.get("dL_dray_planes", (P, 2))
     acc[:, 6:9] = o.get("dL_dnormals", (P, 3)); acc[:, 9:12] = o.get("acc_dmeans2D", (P, 3))
     dc = o.get("acc_dconic", (P, 4)); acc[:, 12] = dc[:, 0]; acc[:, 13] = dc[:, 1]; acc[:, 14] = dc[:, 3]
     acc[:, 15] = o.get("acc_dopacity"); acc[:, 16:19] = o.get("dL_dview_points", (P, 3)); acc[:, 19:25] = o.get("dL_dcamera_planes", (P, 6))
-    out, dsh = hc.preprocess_bwd(s, radii, clb, co[:, 3] if intended else dc[:, 3], acc, eig=eig, eigD=eigD)
+    out, dsh = hc.preprocess_bwd(s, radii, clb, co[:, 3] if intended else dc[:, 3], acc)
     for k, (a, b) in {"dL_dmeans3D": (gr["dL_dmeans3D"], out[:, 0:3]), "dL_dopacity": (gr["dL_dopacity"][:, 0], out[:, 3]),
                       "dL_dcov3D": (gr["dL_dcov3D"], out[:, 4:10]), "dL_dscales": (gr["dL_dscales"], out[:, 10:13]),
                       "dL_drotations": (gr["dL_drotations"], out[:, 13:17]), "dL_dsh": (gr["dL_dsh"], dsh)}.items():

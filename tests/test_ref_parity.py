@@ -94,6 +94,9 @@ def assert_backward_identical(r, o, g):
     go, gr = oracle_backward(o, g), r.grads()
     for n in SUMS:
         assert np.array_equal(bits(r.get(n)), bits(o.get(n))), n
+    # the ninth sum: the render kernel's raw opacity sums, snapshotted between the reference's first and second backward kernel
+    # (ref_api.cpp) -- computeCov2DCUDA rescales the array in place (backward.cu:395-403)
+    assert np.array_equal(bits(r.get("dL_dopacity_raw")), bits(o.get("acc_dopacity"))), "dL_dopacity (raw sum)"
     for k in gr:
         assert gr[k].shape == go[k].shape and np.array_equal(bits(gr[k]), bits(go[k])), k
     return gr
