@@ -191,13 +191,22 @@ def main():
     C.profile_enable(True, only=dom, every=2 if (dom is not None and args.steps >= 8) else 1)   # no warm-up steps: every stage, in the timed region
     C.binning_stats(reset=True)
     Rs, vis = [], []
+    # one event per step boundary on the launch stream (~2 us each, no bubble: nothing waits on them): the spans between them say what a
+    # step costs on the GPU, so that a host stalled by a neighbour (the boxes' hosts are shared) shows up as wall >> median span
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    torch.cuda.reset_peak_memory_stats(dev)
+    mem_before = torch.cuda.memory_allocated(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         R, radii, _ = step()
+        marks[i + 1].record()
         Rs.append(R)
         vis.append(radii)          # kept alive, counted after the timed region
     fence()
     elapsed = time.perf_counter() - t0
+    spans = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    peak_step_bytes = torch.cuda.max_memory_allocated(dev) - mem_before - sum(r.numel() * 4 for r in vis[:-1])
     C.profile_enable(False)
     spec_calls, spec_misses = C.binning_stats()
     timed = C.profile_collect()
@@ -271,11 +280,19 @@ def main():
                               "achieved_GBs_gpu_time": round(ab["total"] / (gpu_ms * 1e-3) / 1e9, 1) if gpu_ms > 0 else 0.0,
                               "achieved_GBs_wall": round(ab["total"] / (ms_per_step * 1e-3) / 1e9, 1),
                               "frac_wall": round(ab["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "step_gpu_span_ms": {"median": round(spans[len(spans) // 2], 4), "min": round(spans[0], 4), "max": round(spans[-1], 4),
+                                 "note": "HIP-event spans between consecutive steps on the launch stream; ms_per_step is the wall clock of the whole region / steps"},
+            "device_memory": {"peak_bytes_of_one_step": int(peak_step_bytes),
+                              "reference_formula_bytes": int(139 * P + 44 * W * H + 24 * R),
+                              "note": "peak torch allocation above the resident inputs during the timed steps (state buffers incl. entry-stream capacity, "
+                                      "outputs, accumulators, gradients); reference: 139 B/Gaussian + 44 B/pixel + 24 B/instance of state "
+                                      "(rasterizer_impl.cu:190-250) without its sort temp, outputs and gradients"},
             "stages_ms": {k: round(v, 4) for k, v in ms.items()},
             "stages_ms_source": "warm-up steps with an event pair per stage; the roofline kernel is re-timed alone inside the timed steps",
             "stage_GBs": {k: round(ab[k] / (grouped[k] * 1e-3) / 1e9, 1) if grouped[k] > 0 else 0.0 for k in grouped},
             # the binning line above divides the REFERENCE algorithm's bytes (6-pass 64-bit sort) by this implementation's time; what the
             # implementation itself moves is about half of that (binning_bytes_moved)
+            "stage_bytes_moved": stage_bytes_moved(tag, args.config, P, W, H, grouped),
             "binning_bytes_moved": {"bytes": int(bmoved), "GBs": round(bmoved / (grouped["binning"] * 1e-3) / 1e9, 1) if grouped["binning"] > 0 else 0.0},
             # the render kernels are gather + ALU bound -- (pixel, list entry) evaluations per second next to their GB/s
             "pairs": {"formulation": pairs["formulation"], "evaluated_per_pass": pairs["evaluated"], "reference_definition_per_pass": pairs["tilewide"],
@@ -312,6 +329,39 @@ def pair_evaluations(C, s, last_state, coord):
         cons = C.debug_export("blk_consumed", torch.int32, 8 * tiles, P, R, W, H, coord, geom, binning, img).to(torch.int64)
         return {"formulation": "entry streams (8x4-pixel blocks)", "evaluated": int(32 * cons.sum().item()), "tilewide": tilewide}
     return {"formulation": "tile-wide lists", "evaluated": tilewide, "tilewide": tilewide}
+
+
+# which stage of the bench line a kernel of the committed PMC pass belongs to (name fragments, profiles/*_pmc_per_kernel.json)
+_STAGE_OF = (("preprocess_fwd_kernel", "preprocess_fwd"), ("preprocess_bwd_kernel", "preprocess_bwd"), ("drgb_clamped", "preprocess_bwd"),
+             ("blend_fwd", "blend_fwd"), ("block_lists", "blend_fwd"), ("balance_blocks", "blend_fwd"), ("blend_bwd", "blend_bwd"),
+             ("digit_histogram", "binning"), ("scan_rows", "binning"), ("scatter_kernel", "binning"), ("gather_block_sums", "binning"),
+             ("gather_scan", "binning"), ("emit_instances", "binning"), ("tile_ranges", "binning"))
+
+
+def stage_bytes_moved(tag, config, P, W, H, grouped_ms):
+    """Per stage: HBM bytes the kernels really moved per step (committed PMC pass: (2 x TCC_EA0_RDREQ + TCC_EA0_WRREQ) x 64 B per dispatch,
+    gfx950 read correction as in pmc_traffic(), x dispatches per step) and the GB/s that makes of this run's stage times -- next to
+    `stage_GBs`, which divides SURVEY 8(d)'s MODEL bytes.  None without a PMC pass for this workload (or one from before round 4, whose
+    summaries merged the sort kernels' names)."""
+    f = _pmc_file(tag, config, P, W, H)
+    if f is None:
+        return None
+    try:
+        d = json.load(open(f))
+        if not any("dispatches_per_step" in v for v in d.values()):
+            return None
+        tot = {}
+        for name, v in d.items():
+            st = next((stg for frag, stg in _STAGE_OF if frag in name), None)
+            if st is None or "TCC_EA0_RDREQ_sum" not in v:
+                continue
+            tot[st] = tot.get(st, 0.0) + v.get("dispatches_per_step", 1.0) * (2 * v["TCC_EA0_RDREQ_sum"] + v["TCC_EA0_WRREQ_sum"]) * 64
+        return {"source": os.path.basename(f),
+                "bytes": {k: int(b) for k, b in tot.items()},
+                "GBs": {k: round(b / (grouped_ms[k] * 1e-3) / 1e9, 1) for k, b in tot.items() if grouped_ms.get(k, 0) > 0},
+                "frac_of_hbm_peak": {k: round(b / (grouped_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, b in tot.items() if grouped_ms.get(k, 0) > 0}}
+    except Exception:
+        return None
 
 
 def _pmc_file(tag, config, P, W, H):

@@ -130,7 +130,7 @@ template <bool MASKS>
 __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32_t* idx_sorted, const uint32_t* offsets,
                                                             const uint32_t* tiles_touched, const float4* splat_a, const int* radii,
                                                             const uint32_t* rect, int gx, int gy, uint32_t* tile_keys, uint32_t* vals,
-                                                            uint32_t cap, uint32_t* ranges_to_clear, uint32_t* count_mirror) {
+                                                            uint32_t cap, uint32_t* ranges_to_clear, uint32_t* count_mirror, uint32_t* stream_tag) {
   // cap: capacity of tile_keys/vals.  With exact allocation it equals num_rendered; in the speculative path (rg_launch.inc)
   // it is a prediction and instances beyond it are dropped here (the host detects the overflow and redoes the binning).
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -141,6 +141,7 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32
     for (int k = i; k < 2 * gx * gy; k += (int)gridDim.x * 256) ranges_to_clear[k] = 0u;
   }
   if (count_mirror && i == 0) __hip_atomic_store(count_mirror, offsets[P - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (i == 0) *stream_tag = MASKS ? kStreamTag : 0u;   // does this image state hold entry streams?  (ImageState::stream_tag)
   const int lane = threadIdx.x & 63;
   uint32_t idx = 0, ntiles = 0, off = 0;
   int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
@@ -801,6 +802,7 @@ struct BlendBwdArgs {
   const float* dL_dpix; const float* dL_dcoord; const float* dL_dmcoord; const float* dL_ddepth; const float* dL_dmdepth;
   const float* dL_dalpha; const float* dL_dnormal;
   float* acc;  // [P][REC] per-Gaussian sums, SplatAcc order
+  const uint32_t* stream_tag;   // ImageState::stream_tag (stream kernels only)
   const uint32_t* blk_consumed; const uint32_t* blk_chunks; const uint32_t* blk_order;   // sub-tile entry streams (rg_streams.inc)
 };
 

@@ -109,6 +109,7 @@ constexpr int kMaskShift = 24;                       // entry streams: instance 
 constexpr uint32_t kGidMask = (1u << kMaskShift) - 1u;
 constexpr int kBlocksPerTile = 8;
 constexpr int kChunkWords = 48;   // 16 x uint2 + 16 x u32
+constexpr uint32_t kStreamTag = 0x53545247u;   // ImageState::stream_tag
 inline size_t stream_chunk_capacity(size_t R, size_t tiles) { return (size_t)kBlocksPerTile * ((R >> 4) + tiles + 1); }
 
 struct ImageState {
@@ -122,6 +123,8 @@ struct ImageState {
   uint32_t* blk_count;     // [8*tiles] entries in each block's list
   uint32_t* blk_consumed;  // [8*tiles] entries of it the forward walked before all of the block's pixels had terminated
   uint32_t* blk_order;     // [8*tiles] block ids (tile*8 + block) in wave order: wave w of the blend kernels walks entries 4w..4w+3
+  uint32_t* stream_tag;    // [4] word 0: kStreamTag when THIS forward wrote entry streams into this buffer, 0 when it did not (written by
+                           // the instance emission of every forward; the stream backward kernels refuse any other value)
   uint32_t* blk_chunks;    // [stream_chunk_capacity(stream_R, tiles) * kChunkWords]
   size_t total;
   static ImageState carve(void* buf, size_t W, size_t H, size_t stream_R = 0) {
@@ -136,6 +139,7 @@ struct ImageState {
     s.blk_count = c.take<uint32_t>(kBlocksPerTile * tiles);
     s.blk_consumed = c.take<uint32_t>(kBlocksPerTile * tiles);
     s.blk_order = c.take<uint32_t>(kBlocksPerTile * tiles);
+    s.stream_tag = c.take<uint32_t>(4);
     s.blk_chunks = c.take<uint32_t>(stream_R ? stream_chunk_capacity(stream_R, tiles) * kChunkWords : 0);
     s.total = c.total();
     return s;

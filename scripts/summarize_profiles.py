@@ -32,9 +32,14 @@ for name in ("pmc_sq", "pmc_tcc"):
     per_kernel = collections.defaultdict(list)
     for r in rows_c:
         if "rg::" in r["Kernel_Name"]:
-            per_kernel[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+            # "void rg::(anonymous namespace)::scatter_kernel<8>(args...)" -> "rg::scatter_kernel<8>": the name up to its argument list
+            # (round 3's summaries cut at the first "(", which merged every kernel of the sort's anonymous namespace into "void rg::")
+            nm = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
+            per_kernel[(nm, r["Counter_Name"])].append(float(r["Counter_Value"]))
+    steps_in_run = int(os.environ.get("PMC_RUN_STEPS", "18"))     # scripts/gpu_profile.sh: --steps 9 --warmup 9
     for (k, c), vals in per_kernel.items():
         agg[k][c] = vals[len(vals) // 2:]
+        out.setdefault(k, {})["dispatches_per_step"] = round(len(vals) / steps_in_run, 3)
     for k, v in agg.items():
         out.setdefault(k, {}).update({c: round(sum(x) / len(x)) for c, x in v.items()})
 for k, v in out.items():

@@ -87,3 +87,20 @@ def test_executed_backward_matches_the_reference_semantics(ks, coord, depth, see
             assert np.abs(term_h).max() <= 1e-2 * scale and tsize <= 3e-3 * scale, (k, report[k])
             assert np.abs(a_exe - b_exe).max() <= ATOL + 1e-2 * scale, (k, report[k])
     print("executed-mode gradients (fractions of each tensor's scale):", report)
+    # What the bands above cannot say at kernel_size 0 -- that the per-Gaussian chain itself is right in the EXECUTED mode -- the
+    # decomposition says element-wise: the per-Gaussian half of the backward over the oracle's own per-Gaussian sums
+    # (radegs_backward_from_sums) returns the oracle's executed-mode gradients at 1e-5 / 1e-4, every tensor, both kernel sizes.
+    from gpu_util import HipRun, backward_from_sums, reference_sums
+    orc.set_opacity_slip(1)
+    o = oracle_for(s, nthreads=1)
+    o.forward()
+    want = oracle_backward(o, g)
+    h = HipRun(s, "cuda:0")
+    h.forward_native()
+    half = backward_from_sums(h, reference_sums(o.get, s.means3D.shape[0], coord, raw_opacity="acc_dopacity"))
+    for k in GEOM + ("dL_dmeans2D", "dL_dopacity", "dL_dsh"):
+        if half.get(k) is None:
+            continue
+        b = want[k].reshape(half[k].shape)
+        bad = ~close(half[k], b)
+        assert not bad.any(), (k, int(bad.sum()), float(np.abs(half[k] - b).max()), float(np.abs(b).max()))

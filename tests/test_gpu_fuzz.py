@@ -1,7 +1,7 @@
 """Randomised parity sweep: scene density, image shapes that are not multiples of the tile, SH degree, 2D-filter size,
 output modes, background colour, scale_modifier, camera pose, opacity regime -- forward indices exact, images within
-tolerance, gradients by the criteria of test_gpu_parity.check_backward with widened noise factors (small random scenes have
-short, cancelling per-Gaussian sums).  Seeds are fixed, so a failure reproduces."""
+tolerance, gradients by the criteria of test_gpu_parity.check_backward: the standard ones for scenes of at least 2 000 Gaussians,
+widened noise factors below (short, cancelling per-Gaussian sums).  Seeds are fixed, so a failure reproduces."""
 import numpy as np
 import pytest
 import torch
@@ -31,12 +31,15 @@ _SPEC = os.environ.get("RADEGS_FUZZ_SEEDS", "0:14")
 _SEEDS = [int(v) for v in _SPEC.split(",")] if "," in _SPEC else list(range(*(int(v) for v in _SPEC.split(":"))))
 
 
-# Gradient criteria of the sweep (check_backward): >= 97 % of every tensor's elements inside the strict 1e-5 / 1e-4 bar, the rest
-# inside 4x the fp32 noise band; against the fp64 oracle at most 1.5x the fp32 oracle's own rms error and 2x its max error.  The
-# standard scenes of test_gpu_parity.py use 0.99 / 1x / 1.1 / 1.25; scenes of a few hundred Gaussians make those statistics noisy
-# (the fp32 oracle's own error is ONE random draw of rounding, the HIP path's another), which is all the widening covers: 40 seeds
-# pass these bounds in either blend path, 35 of 40 pass the standard ones (RADEGS_FUZZ_THRESH overrides for such experiments).
-_THRESH = [float(v) for v in os.environ.get("RADEGS_FUZZ_THRESH", "0.97,1.5,2.0,4.0").split(",")]
+# Gradient criteria of the sweep (check_backward) as a FUNCTION OF SCENE SIZE.  Scenes of at least 2 000 Gaussians run the standard
+# criteria of test_gpu_parity.py -- >= 99 % of every tensor's elements inside the strict 1e-5 / 1e-4 bar, the rest inside the fp32 noise
+# band; against the fp64 oracle at most 1.1x the fp32 oracle's own rms error and 1.25x its max error.  Below that the statistics
+# themselves are noisy (the fp32 oracle's error is ONE random draw of rounding over a few hundred short, cancelling sums, the HIP
+# path's another): 0.97 / 4x band / 1.5x rms / 2x max.  The split is the measured one: of 40 seeds at the standard criteria the four
+# that fail have 306, 627, 961 and 1 261 Gaussians, and they fail identically with a build whose blend backward uses the specified
+# exponential and an IEEE division (profiles/r03_fuzz_table_*.txt).  RADEGS_FUZZ_THRESH overrides both (experiments).
+_STANDARD, _SMALL_SCENE, _SMALL_BELOW = (0.99, 1.1, 1.25, 1.0), (0.97, 1.5, 2.0, 4.0), 2000
+_FORCED = [float(v) for v in os.environ["RADEGS_FUZZ_THRESH"].split(",")] if os.environ.get("RADEGS_FUZZ_THRESH") else None
 
 
 def _run(seed):
@@ -45,8 +48,8 @@ def _run(seed):
         kw["P"] = min(kw["P"], 2500)  # heavy overdraw: keep the oracle's backward in seconds
     s = make_scene(**kw)
     o, h = check_forward(s, scale_modifier=scale_modifier)
-    check_backward(s, o, seed=seed, min_strict=_THRESH[0], scale_modifier=scale_modifier, rms_factor=_THRESH[1], max_factor=_THRESH[2],
-                   band_factor=_THRESH[3])
+    t = _FORCED or (_STANDARD if kw["P"] >= _SMALL_BELOW else _SMALL_SCENE)
+    check_backward(s, o, seed=seed, min_strict=t[0], scale_modifier=scale_modifier, rms_factor=t[1], max_factor=t[2], band_factor=t[3])
 
 
 @pytest.mark.parametrize("seed", _SEEDS)
