@@ -64,8 +64,10 @@ def binning_bytes_moved(P, R, tiles, streams):
     """What THIS implementation's binning moves, as opposed to the reference algorithm's 16 P + 164 R that
     `algorithmic_bytes` charges: depth sort of P 32-bit keys, 4 passes x (histogram reads the key, scatter reads key (+ value after
     the first pass) and writes both) = 76 P; gather-scan 20 P; emission reads 12 P (index, offset, packed rectangle) + the 64-B record
-    of every visible splat when block masks are computed, writes 8 R; tile sort 2 passes x 20 R; ranges 4 R + 8 tiles."""
-    return 76 * P + 20 * P + 12 * P + 8 * R + 40 * R + 4 * R + 8 * tiles + (64 * P if streams else 0)
+    of every visible splat when block masks are computed, writes 6 R (16-bit tile key + value; 8 R above 65 536 tiles); tile sort
+    2 passes x 14 R (20 R with 32-bit keys); ranges 2 R + 8 tiles."""
+    k = 2 if tiles <= 65535 and os.environ.get("RADEGS_KEY16", "1") != "0" else 4
+    return 76 * P + 20 * P + 12 * P + (4 + k) * R + 2 * (8 + 3 * k) * R + k * R + 8 * tiles + (64 * P if streams else 0)
 
 
 def main():

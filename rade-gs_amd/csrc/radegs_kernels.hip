@@ -130,7 +130,9 @@ template <bool MASKS>
 __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32_t* idx_sorted, const uint32_t* offsets,
                                                             const uint32_t* tiles_touched, const float4* splat_a, const int* radii,
                                                             const uint32_t* rect, int gx, int gy, uint32_t* tile_keys, uint32_t* vals,
-                                                            uint32_t cap, uint32_t* ranges_to_clear, uint32_t* count_mirror, uint32_t* stream_tag) {
+                                                            uint32_t cap, uint32_t* ranges_to_clear, uint32_t* count_mirror, uint32_t* stream_tag, int key16) {
+  // key16: tile ids leave as 16-bit keys (grids of at most 65 536 tiles): the tile sort then moves a third less (radegs_sort.hip)
+  uint16_t* const tile_keys16 = reinterpret_cast<uint16_t*>(tile_keys);
   // cap: capacity of tile_keys/vals.  With exact allocation it equals num_rendered; in the speculative path (rg_launch.inc)
   // it is a prediction and instances beyond it are dropped here (the host detects the overflow and redoes the binning).
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -194,7 +196,7 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32
             }
             v |= mask << kMaskShift;
           }
-          tile_keys[off] = (uint32_t)(y * gx + x);
+          if (key16) tile_keys16[off] = (uint16_t)(y * gx + x); else tile_keys[off] = (uint32_t)(y * gx + x);
           vals[off] = v;
         }
         off++;
@@ -218,14 +220,15 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32
         uint32_t v = g_idx;
         if constexpr (MASKS)
           v |= ellipse_block_mask(g_mx, g_my, g_cx, g_cy, g_cz, g_thr, (float)((g_x0 + tx) * 16), (float)((g_y0 + ty) * 16)) << kMaskShift;
-        tile_keys[g_off + t] = (uint32_t)((g_y0 + ty) * gx + (g_x0 + tx));
+        if (key16) tile_keys16[g_off + t] = (uint16_t)((g_y0 + ty) * gx + (g_x0 + tx)); else tile_keys[g_off + t] = (uint32_t)((g_y0 + ty) * gx + (g_x0 + tx));
         vals[g_off + t] = v;
       }
     }
   }
 }
 
-__global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint32_t* keys, uint2* ranges, const uint32_t* L_dev) {
+template <class K>
+__global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const K* keys, uint2* ranges, const uint32_t* L_dev) {
   if (L_dev) L = (int)min((uint32_t)L, *L_dev);  // capacity launch, see emit_instances_kernel
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= L) return;

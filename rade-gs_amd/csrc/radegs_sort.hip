@@ -27,8 +27,10 @@ namespace {
 constexpr int kSortThreads = 256;                 // 4 waves
 constexpr int kBins = 256;
 
-template <int ITEMS>
-__global__ void __launch_bounds__(kSortThreads) digit_histogram_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
+// K: key type -- uint32_t (depth keys, tile ids of grids above 65 536 tiles) or uint16_t (tile ids: 13 bits at 1080p, 15 at 4K; a third
+// less traffic per pass -- histogram 2 B, scatter 6 B in + 6 B out per item instead of 4 / 8 / 8).
+template <int ITEMS, class K>
+__global__ void __launch_bounds__(kSortThreads) digit_histogram_kernel(const K* __restrict__ keys, uint32_t n, int shift,
                                                                        uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblocks,
                                                                        const uint32_t* __restrict__ n_dev) {
   __shared__ uint32_t h[kBins];
@@ -40,7 +42,7 @@ __global__ void __launch_bounds__(kSortThreads) digit_histogram_kernel(const uin
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
     const uint32_t i = base + r * kSortThreads + threadIdx.x;
-    k[r] = i < n ? keys[i] : 0u;
+    k[r] = i < n ? (uint32_t)keys[i] : 0u;
   }
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
@@ -97,9 +99,9 @@ __device__ __forceinline__ uint32_t block256_exclusive(uint32_t t, uint32_t* tmp
   return off + x - t;
 }
 
-template <int ITEMS>
-__global__ void __launch_bounds__(kSortThreads) scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                               uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
+template <int ITEMS, class K>
+__global__ void __launch_bounds__(kSortThreads) scatter_kernel(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                               K* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
                                                                int shift, uint32_t mask, int nbits, const uint32_t* __restrict__ hist,
                                                                uint32_t nblocks, const uint32_t* __restrict__ totals,
                                                                const uint32_t* __restrict__ n_dev) {
@@ -109,7 +111,7 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const uint32_t* _
   __shared__ uint32_t local_start[kBins];     // position of each digit's first item in the block-local sorted order
   __shared__ uint32_t wave_cnt[4][kBins];     // histogram of each wave's run, then running rank counters
   __shared__ uint32_t scan_tmp[4];
-  __shared__ uint32_t lds_k[BLOCK_ITEMS];     // the block's items reordered by digit (stable), so that the global
+  __shared__ K lds_k[BLOCK_ITEMS];            // the block's items reordered by digit (stable), so that the global
   __shared__ uint32_t lds_v[BLOCK_ITEMS];     // writes below go out in contiguous per-digit runs
   // ITEMS = 32 (tens of millions of items, C5): 2 x 32 KB + 6 KB of counters = 70 KB of LDS per workgroup -- above the 64 KB of every
   // AMD architecture before gfx950 (160 KB per CU).  This library is built for gfx950 only (build.py: ARCH).
@@ -126,7 +128,7 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const uint32_t* _
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
     const uint32_t i = run0 + r * 64 + lane;
-    rk[r] = i < n ? keys_in[i] : 0xFFFFFFFFu;
+    rk[r] = i < n ? (uint32_t)keys_in[i] : 0xFFFFFFFFu;
   }
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const uint32_t* _
     __builtin_amdgcn_wave_barrier();
     if (valid) {
       const uint32_t pos = local_start[digit] + before + rank_in_step;
-      lds_k[pos] = key;
+      lds_k[pos] = (K)key;
       lds_v[pos] = val;
     }
   }
@@ -185,10 +187,10 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const uint32_t* _
   // ---- write out: consecutive local positions of one digit are consecutive global addresses ----
   const uint32_t count = block0 < n ? min((uint32_t)BLOCK_ITEMS, n - block0) : 0u;
   for (uint32_t pos = tid; pos < count; pos += kSortThreads) {
-    const uint32_t key = lds_k[pos];
+    const uint32_t key = (uint32_t)lds_k[pos];
     const uint32_t digit = (key >> shift) & mask;
     const uint32_t dst = digit_base[digit] + (pos - local_start[digit]);
-    keys_out[dst] = key;
+    keys_out[dst] = (K)key;
     vals_out[dst] = lds_v[pos];
   }
 }
@@ -291,8 +293,9 @@ size_t sort_temp_bytes(size_t n) {
 // "values are 0..n-1".  keys_in/vals_in are left untouched; temp must hold sort_temp_bytes(n).
 // n_dev != nullptr: n is a CAPACITY (it sizes the grid and the temp storage) and the number of valid items is min(n, *n_dev),
 // read on the device -- the caller does not have to wait for it.
-hipError_t radix_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
-                                uint32_t* vals_out, size_t n, int end_bit, hipStream_t stream, const uint32_t* n_dev) {
+template <class K>
+static hipError_t radix_sort_pairs(void* temp, size_t temp_bytes, const K* keys_in, K* keys_out, const uint32_t* vals_in,
+                                   uint32_t* vals_out, size_t n, int end_bit, hipStream_t stream, const uint32_t* n_dev) {
   if (n == 0) return hipSuccess;
   if (temp_bytes < sort_temp_bytes(n)) return hipErrorInvalidValue;
   if (n > 0xFFFFFFFFull - 65536) return hipErrorInvalidValue;
@@ -300,13 +303,13 @@ hipError_t radix_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* k
   const uint32_t nblocks = (uint32_t)((n + (size_t)kSortThreads * items - 1) / ((size_t)kSortThreads * items));
   char* p = static_cast<char*>(temp);
   auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~size_t(255); return r; };
-  uint32_t* tkeys = reinterpret_cast<uint32_t*>(take(n * sizeof(uint32_t)));
+  K* tkeys = reinterpret_cast<K*>(take(n * sizeof(uint32_t)));
   uint32_t* tvals = reinterpret_cast<uint32_t*>(take(n * sizeof(uint32_t)));
   uint32_t* hist = reinterpret_cast<uint32_t*>(take((size_t)kBins * nblocks * sizeof(uint32_t)));
   uint32_t* totals = reinterpret_cast<uint32_t*>(take(kBins * sizeof(uint32_t)));
   const int passes = (end_bit + 7) / 8;
   const int width = (end_bit + passes - 1) / passes;  // balanced digits: 13 bits -> 7 + 6, 32 -> 8 x 4
-  const uint32_t* src_k = keys_in;
+  const K* src_k = keys_in;
   const uint32_t* src_v = vals_in;
   for (int pass = 0; pass < passes; pass++) {
     const int shift = pass * width;
@@ -314,14 +317,14 @@ hipError_t radix_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* k
     const uint32_t mask = (1u << nbits) - 1u;
     // destinations alternate so that the LAST pass lands in (keys_out, vals_out)
     const bool to_out = ((passes - 1 - pass) % 2) == 0;
-    uint32_t* dst_k = to_out ? keys_out : tkeys;
+    K* dst_k = to_out ? keys_out : tkeys;
     uint32_t* dst_v = to_out ? vals_out : tvals;
 #define RG_SORT_PASS(I_)                                                                                                                   \
   do {                                                                                                                                     \
-    hipLaunchKernelGGL(digit_histogram_kernel<I_>, dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, (uint32_t)n, shift, mask, hist,  \
+    hipLaunchKernelGGL((digit_histogram_kernel<I_, K>), dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, (uint32_t)n, shift, mask, hist,  \
                        nblocks, n_dev);                                                                                                    \
     hipLaunchKernelGGL(scan_rows_kernel, dim3(kBins), dim3(kSortThreads), 0, stream, hist, nblocks, totals);                               \
-    hipLaunchKernelGGL(scatter_kernel<I_>, dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, src_v, dst_k, dst_v, (uint32_t)n, shift,  \
+    hipLaunchKernelGGL((scatter_kernel<I_, K>), dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, src_v, dst_k, dst_v, (uint32_t)n, shift,  \
                        mask, nbits, hist, nblocks, totals, n_dev);                                                                         \
   } while (0)
     if (items == 32) RG_SORT_PASS(32);
@@ -332,6 +335,17 @@ hipError_t radix_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* k
     src_v = dst_v;
   }
   return hipGetLastError();
+}
+
+hipError_t radix_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
+                                uint32_t* vals_out, size_t n, int end_bit, hipStream_t stream, const uint32_t* n_dev) {
+  return radix_sort_pairs<uint32_t>(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, end_bit, stream, n_dev);
+}
+// the same sort over 16-bit keys (end_bit <= 16)
+hipError_t radix_sort_pairs_u16(void* temp, size_t temp_bytes, const uint16_t* keys_in, uint16_t* keys_out, const uint32_t* vals_in,
+                                uint32_t* vals_out, size_t n, int end_bit, hipStream_t stream, const uint32_t* n_dev) {
+  if (end_bit > 16) return hipErrorInvalidValue;
+  return radix_sort_pairs<uint16_t>(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, end_bit, stream, n_dev);
 }
 
 }  // namespace rg
