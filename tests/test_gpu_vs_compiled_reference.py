@@ -57,9 +57,16 @@ def test_hip_equals_the_references_own_code(coord, depth, ks, full):
         del want
         r.backward(g["color"], g["coord"], g["mcoord"], g["depth"], g["mdepth"], g["alpha"], g["normal"])
         want_g = r.grads()
+        import diff_gaussian_rasterization._C as C
         h2 = HipRun(s, "cuda:0")
         h2.forward()
-        got = h2.backward(g)
+        C.KEEP_ACC = True            # the blend backward's per-Gaussian accumulator records stay readable (compared below)
+        try:
+            got = h2.backward(g)
+            acc = C.LAST_ACC
+        finally:
+            C.KEEP_ACC = False
+            C.LAST_ACC = None
         for k in ("dL_dmeans2D", "dL_dopacity", "dL_dsh"):
             b = want_g[k].reshape(got[k].shape)
             scale = float(np.abs(b).max()) + 1e-30
@@ -82,16 +89,7 @@ def test_hip_equals_the_references_own_code(coord, depth, ks, full):
             bad = ~close(got2[k], b)
             assert not bad.any(), (f"{k} from the reference's sums: {int(bad.sum())} of {bad.size} elements outside 1e-5/1e-4, "
                                    f"max |diff| {float(np.abs(got2[k] - b).max()):.3e}, scale {float(np.abs(b).max()):.3e}")
-        import diff_gaussian_rasterization._C as C
-        C.KEEP_ACC = True
-        try:
-            h3 = HipRun(s, "cuda:0")
-            h3.forward()
-            got3 = h3.backward(g)
-            mine = hip_sums_as_reference(C.LAST_ACC, s)
-        finally:
-            C.KEEP_ACC = False
-            C.LAST_ACC = None
+        mine = hip_sums_as_reference(acc, s)
         vis = r.get("radii") > 0
         cols = {"dL_dcolors": slice(0, 3), "dL_dts": slice(3, 4), "dL_dray_planes": slice(4, 6), "dL_dnormals": slice(6, 9),
                 "dL_dmeans2D": slice(9, 12), "dL_dconic": slice(12, 15), "dL_dopacity_raw": slice(15, 16)}
@@ -103,7 +101,7 @@ def test_hip_equals_the_references_own_code(coord, depth, ks, full):
             assert frac_close(a_, b_) > 0.99, (k, frac_close(a_, b_))
             assert close(a_, b_, atol=ATOL + 1e-4 * scale, rtol=1e-3).all(), (k, float(np.abs(a_ - b_).max()), scale)
         for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations"):
-            assert np.isfinite(got[k]).all() and np.isfinite(got3[k]).all(), k
+            assert np.isfinite(got[k]).all(), k
     finally:
         ref.set_exp("libm")
         ref.set_num_threads(1)
