@@ -286,9 +286,11 @@ def main():
                                  "note": "HIP-event spans between consecutive steps on the launch stream; ms_per_step is the wall clock of the whole region / steps"},
             "device_memory": {"peak_bytes_of_one_step": int(peak_step_bytes),
                               "reference_formula_bytes": int(139 * P + 44 * W * H + 24 * R),
+                              "reference_with_outputs_and_gradients_bytes": int(139 * P + 44 * W * H + 24 * R + 60 * W * H + 360 * P),
                               "note": "peak torch allocation above the resident inputs during the timed steps (state buffers incl. entry-stream capacity, "
                                       "outputs, accumulators, gradients); reference: 139 B/Gaussian + 44 B/pixel + 24 B/instance of state "
-                                      "(rasterizer_impl.cu:190-250) without its sort temp, outputs and gradients"},
+                                      "(rasterizer_impl.cu:190-250); second figure: plus its 15 output planes (60 B/pixel) and its gradient / per-Gaussian "
+                                      "sum tensors (360 B/Gaussian at SH degree 3, rasterize_points.cu:175-193), still without its sort temp"},
             "stages_ms": {k: round(v, 4) for k, v in ms.items()},
             "stages_ms_source": "warm-up steps with an event pair per stage; the roofline kernel is re-timed alone inside the timed steps",
             "stage_GBs": {k: round(ab[k] / (grouped[k] * 1e-3) / 1e9, 1) if grouped[k] > 0 else 0.0 for k in grouped},

@@ -27,6 +27,7 @@ for step in "$@"; do
 import json
 rows = [json.loads(l) for l in open("gpurun_out/cold_first_launch.jsonl") if l.startswith("{")]
 rows = [r for r in rows if r.get("tag") == "${TAG}"]
+open("gpurun_out/cold_${TAG}.jsonl", "w").write("".join(json.dumps(r) + "\n" for r in rows))   # per call: the merge back does not append
 print("cold: %d processes, %d clean, first_on_box in %d, mismatches: %s" % (len(rows), sum(r["ok"] for r in rows), sum(r["first_on_box"] for r in rows), [r.get("differs") for r in rows if not r["ok"]]))
 PY
       ;;
