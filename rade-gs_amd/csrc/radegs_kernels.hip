@@ -58,6 +58,7 @@ __device__ __forceinline__ Camera load_camera(const CamArgs& a) {
 }
 
 // =========================================================================== preprocess ==
+constexpr uint32_t kDepthKeyBase = 0x3E4CCCCDu;   // bits(0.2f): every visible Gaussian lies beyond the near plane (auxiliary.h:166)
 struct PreFwdArgs {
   int P, D, M;
   const float* means3D; const float* scales; const float* rotations; const float* cov3D_precomp;
@@ -67,6 +68,7 @@ struct PreFwdArgs {
   int* radii; float4* splat_a; float4* splat_b; uint32_t* tiles_touched; uint32_t* depth_key; uint8_t* clamped;
   float4* inte_rec;  // [P][2] {icr0..icr3 | icr4, icr5, well, 0}; INTE kernel only
   uint32_t* rect;    // [P] packed tile rectangle
+  uint32_t* key_overflow;   // mapped host word (or null): set when a visible depth key does not fit the 27-bit window of the 3-pass sort
 };
 
 template <bool INTE>
@@ -85,6 +87,10 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(const PreFwdArgs a)
   a.rect[idx] = s.radius > 0 ? s.rect : 0u;
   // positive floats order like unsigned ints; invisible Gaussians sort to the very end
   a.depth_key[idx] = s.radius > 0 ? __float_as_uint(s.depth) : 0xFFFFFFFFu;
+  // the depth sort runs three 9-bit passes over (key - bits(0.2f)) when every visible key fits 27 bits, i.e. z < 13 107 (rg_launch.inc);
+  // a key outside raises the flag the host looks at before it trusts the order (and redoes the forward with the 4-pass sort)
+  if (a.key_overflow && s.radius > 0 && __float_as_uint(s.depth) - kDepthKeyBase >= (1u << 27))
+    __hip_atomic_store(a.key_overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (s.radius > 0) {
     float4* ra = a.splat_a + 4 * (size_t)idx;
     ra[0] = make_float4(s.mx, s.my, s.cx, s.cy);

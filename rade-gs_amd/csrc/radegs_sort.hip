@@ -29,13 +29,16 @@ constexpr int kBins = 256;
 
 // K: key type -- uint32_t (depth keys, tile ids of grids above 65 536 tiles) or uint16_t (tile ids: 13 bits at 1080p, 15 at 4K; a third
 // less traffic per pass -- histogram 2 B, scatter 6 B in + 6 B out per item instead of 4 / 8 / 8).
-template <int ITEMS, class K>
+// BINS: 256 (digits of up to 8 bits) or 512 (9-bit digits: the 27-bit depth sort in three passes).  key_base: subtracted from every key
+// before its digit is taken (the depth sort's keys are float bits above bits(0.2f); stored keys stay as they are).
+template <int ITEMS, class K, int BINS>
 __global__ void __launch_bounds__(kSortThreads) digit_histogram_kernel(const K* __restrict__ keys, uint32_t n, int shift,
                                                                        uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblocks,
-                                                                       const uint32_t* __restrict__ n_dev) {
-  __shared__ uint32_t h[kBins];
+                                                                       const uint32_t* __restrict__ n_dev, uint32_t key_base) {
+  __shared__ uint32_t h[BINS];
   if (n_dev) n = min(n, *n_dev);  // capacity launch: the real count is still on the device (rg_launch.inc, speculative binning)
-  h[threadIdx.x] = 0;
+#pragma unroll
+  for (int d = threadIdx.x; d < BINS; d += kSortThreads) h[d] = 0;
   __syncthreads();
   const uint32_t base = blockIdx.x * (uint32_t)(kSortThreads * ITEMS);
   uint32_t k[ITEMS];   // every load is issued before the first one is used (a load per LDS atomic would serialise their latencies)
@@ -47,10 +50,11 @@ __global__ void __launch_bounds__(kSortThreads) digit_histogram_kernel(const K* 
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
     const uint32_t i = base + r * kSortThreads + threadIdx.x;
-    if (i < n) atomicAdd(&h[(k[r] >> shift) & mask], 1u);
+    if (i < n) atomicAdd(&h[((k[r] - key_base) >> shift) & mask], 1u);
   }
   __syncthreads();
-  hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];  // [digit][block]
+#pragma unroll
+  for (int d = threadIdx.x; d < BINS; d += kSortThreads) hist[(size_t)d * nblocks + blockIdx.x] = h[d];  // [digit][block]
 }
 
 // One workgroup per digit: exclusive scan of that digit's per-block counts (in place) + the digit's total.
@@ -99,27 +103,40 @@ __device__ __forceinline__ uint32_t block256_exclusive(uint32_t t, uint32_t* tmp
   return off + x - t;
 }
 
-template <int ITEMS, class K>
+template <int ITEMS, class K, int BINS>
 __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                K* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
                                                                int shift, uint32_t mask, int nbits, const uint32_t* __restrict__ hist,
                                                                uint32_t nblocks, const uint32_t* __restrict__ totals,
-                                                               const uint32_t* __restrict__ n_dev) {
+                                                               const uint32_t* __restrict__ n_dev, uint32_t key_base) {
   constexpr int BLOCK_ITEMS = kSortThreads * ITEMS, WAVE_ITEMS = 64 * ITEMS;
+  constexpr int PER = BINS / kSortThreads;    // consecutive digits per thread in the table work (1 or 2)
   if (n_dev) n = min(n, *n_dev);
-  __shared__ uint32_t digit_base[kBins];      // global offset of this block's first item of each digit
-  __shared__ uint32_t local_start[kBins];     // position of each digit's first item in the block-local sorted order
-  __shared__ uint32_t wave_cnt[4][kBins];     // histogram of each wave's run, then running rank counters
+  __shared__ uint32_t digit_base[BINS];       // global offset of this block's first item of each digit
+  __shared__ uint32_t local_start[BINS];      // position of each digit's first item in the block-local sorted order
+  __shared__ uint32_t wave_cnt[4][BINS];      // histogram of each wave's run, then running rank counters
   __shared__ uint32_t scan_tmp[4];
   __shared__ K lds_k[BLOCK_ITEMS];            // the block's items reordered by digit (stable), so that the global
   __shared__ uint32_t lds_v[BLOCK_ITEMS];     // writes below go out in contiguous per-digit runs
   // ITEMS = 32 (tens of millions of items, C5): 2 x 32 KB + 6 KB of counters = 70 KB of LDS per workgroup -- above the 64 KB of every
   // AMD architecture before gfx950 (160 KB per CU).  This library is built for gfx950 only (build.py: ARCH).
-  static_assert(2 * BLOCK_ITEMS * sizeof(uint32_t) + 8 * kBins * sizeof(uint32_t) <= 160 * 1024, "scatter_kernel: LDS footprint exceeds gfx950's 160 KB");
+  static_assert(2 * BLOCK_ITEMS * sizeof(uint32_t) + 8 * BINS * sizeof(uint32_t) <= 160 * 1024, "scatter_kernel: LDS footprint exceeds gfx950's 160 KB");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  digit_base[tid] = block256_exclusive(totals[tid], scan_tmp) + hist[(size_t)tid * nblocks + blockIdx.x];
+  {   // exclusive scan of the digit totals (thread t owns digits PER t .. PER t + PER - 1) + this block's offset inside each digit
+    uint32_t tot[PER], sum = 0;
 #pragma unroll
-  for (int w = 0; w < 4; w++) wave_cnt[w][tid] = 0;
+    for (int q = 0; q < PER; q++) { tot[q] = totals[PER * tid + q]; sum += tot[q]; }
+    uint32_t ex = block256_exclusive(sum, scan_tmp);
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      digit_base[PER * tid + q] = ex + hist[(size_t)(PER * tid + q) * nblocks + blockIdx.x];
+      ex += tot[q];
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < 4; w++)
+#pragma unroll
+    for (int q = 0; q < PER; q++) wave_cnt[w][PER * tid + q] = 0;
   __syncthreads();
   const uint32_t block0 = blockIdx.x * (uint32_t)BLOCK_ITEMS;
   const uint32_t run0 = block0 + wave * (uint32_t)WAVE_ITEMS;  // this wave's contiguous run
@@ -139,18 +156,28 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const K* __restri
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
     const uint32_t i = run0 + r * 64 + lane;
-    if (i < n) atomicAdd(&wave_cnt[wave][(rk[r] >> shift) & mask], 1u);
+    if (i < n) atomicAdd(&wave_cnt[wave][((rk[r] - key_base) >> shift) & mask], 1u);
   }
   __syncthreads();
   // per digit: the 4 wave counts become exclusive prefixes (wave w starts after waves < w); block total per digit
-  uint32_t block_count = 0;
+  {
+    uint32_t bc[PER], sum = 0;
 #pragma unroll
-  for (int w = 0; w < 4; w++) {
-    const uint32_t c = wave_cnt[w][tid];
-    wave_cnt[w][tid] = block_count;
-    block_count += c;
+    for (int q = 0; q < PER; q++) {
+      uint32_t block_count = 0;
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        const uint32_t c = wave_cnt[w][PER * tid + q];
+        wave_cnt[w][PER * tid + q] = block_count;
+        block_count += c;
+      }
+      bc[q] = block_count;
+      sum += block_count;
+    }
+    uint32_t ex = block256_exclusive(sum, scan_tmp);
+#pragma unroll
+    for (int q = 0; q < PER; q++) { local_start[PER * tid + q] = ex; ex += bc[q]; }
   }
-  local_start[tid] = block256_exclusive(block_count, scan_tmp);
   __syncthreads();
   // ---- phase B: stable ranks, 64 consecutive items per step; items land in LDS in digit order ----
 #pragma unroll
@@ -159,7 +186,7 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const K* __restri
     const bool valid = i < n;
     const uint32_t key = rk[r];
     const uint32_t val = rv[r];
-    const uint32_t digit = (key >> shift) & mask;
+    const uint32_t digit = ((key - key_base) >> shift) & mask;
     // lanes holding the same digit (invalid lanes only match each other and are never counted)
     uint64_t peers = __ballot(valid);
     if (!valid) peers = ~peers;
@@ -188,7 +215,7 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const K* __restri
   const uint32_t count = block0 < n ? min((uint32_t)BLOCK_ITEMS, n - block0) : 0u;
   for (uint32_t pos = tid; pos < count; pos += kSortThreads) {
     const uint32_t key = (uint32_t)lds_k[pos];
-    const uint32_t digit = (key >> shift) & mask;
+    const uint32_t digit = ((key - key_base) >> shift) & mask;
     const uint32_t dst = digit_base[digit] + (pos - local_start[digit]);
     keys_out[dst] = (K)key;
     vals_out[dst] = lds_v[pos];
@@ -285,8 +312,8 @@ static int sort_items_per_thread(size_t n) {
 
 size_t sort_temp_bytes(size_t n) {
   const size_t nblocks = (n + kSortThreads * 8 - 1) / (kSortThreads * 8);  // upper bound over both block sizes
-  // ping-pong keys + values, [256][nblocks] histogram, 256 totals
-  return 2 * (n * sizeof(uint32_t) + 256) + (kBins * (nblocks + 1)) * sizeof(uint32_t) + kBins * sizeof(uint32_t) + 1024;
+  // ping-pong keys + values, [512][nblocks] histogram (9-bit digits; 256 rows otherwise), 512 totals
+  return 2 * (n * sizeof(uint32_t) + 256) + (2 * kBins * (nblocks + 1)) * sizeof(uint32_t) + 2 * kBins * sizeof(uint32_t) + 1024;
 }
 
 // Sorts (keys_in, vals_in) by bits [0, end_bit) of the key into (keys_out, vals_out).  vals_in == nullptr means
@@ -295,7 +322,8 @@ size_t sort_temp_bytes(size_t n) {
 // read on the device -- the caller does not have to wait for it.
 template <class K>
 static hipError_t radix_sort_pairs(void* temp, size_t temp_bytes, const K* keys_in, K* keys_out, const uint32_t* vals_in,
-                                   uint32_t* vals_out, size_t n, int end_bit, hipStream_t stream, const uint32_t* n_dev) {
+                                   uint32_t* vals_out, size_t n, int end_bit, hipStream_t stream, const uint32_t* n_dev,
+                                   uint32_t key_base = 0, int digit_bits = 8) {
   if (n == 0) return hipSuccess;
   if (temp_bytes < sort_temp_bytes(n)) return hipErrorInvalidValue;
   if (n > 0xFFFFFFFFull - 65536) return hipErrorInvalidValue;
@@ -305,9 +333,10 @@ static hipError_t radix_sort_pairs(void* temp, size_t temp_bytes, const K* keys_
   auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~size_t(255); return r; };
   K* tkeys = reinterpret_cast<K*>(take(n * sizeof(uint32_t)));
   uint32_t* tvals = reinterpret_cast<uint32_t*>(take(n * sizeof(uint32_t)));
-  uint32_t* hist = reinterpret_cast<uint32_t*>(take((size_t)kBins * nblocks * sizeof(uint32_t)));
-  uint32_t* totals = reinterpret_cast<uint32_t*>(take(kBins * sizeof(uint32_t)));
-  const int passes = (end_bit + 7) / 8;
+  const int bins = digit_bits > 8 ? 512 : 256;
+  uint32_t* hist = reinterpret_cast<uint32_t*>(take((size_t)bins * nblocks * sizeof(uint32_t)));
+  uint32_t* totals = reinterpret_cast<uint32_t*>(take(bins * sizeof(uint32_t)));
+  const int passes = (end_bit + digit_bits - 1) / digit_bits;
   const int width = (end_bit + passes - 1) / passes;  // balanced digits: 13 bits -> 7 + 6, 32 -> 8 x 4
   const K* src_k = keys_in;
   const uint32_t* src_v = vals_in;
@@ -319,17 +348,23 @@ static hipError_t radix_sort_pairs(void* temp, size_t temp_bytes, const K* keys_
     const bool to_out = ((passes - 1 - pass) % 2) == 0;
     K* dst_k = to_out ? keys_out : tkeys;
     uint32_t* dst_v = to_out ? vals_out : tvals;
-#define RG_SORT_PASS(I_)                                                                                                                   \
+#define RG_SORT_PASS_B(I_, B_)                                                                                                             \
   do {                                                                                                                                     \
-    hipLaunchKernelGGL((digit_histogram_kernel<I_, K>), dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, (uint32_t)n, shift, mask, hist,  \
-                       nblocks, n_dev);                                                                                                    \
-    hipLaunchKernelGGL(scan_rows_kernel, dim3(kBins), dim3(kSortThreads), 0, stream, hist, nblocks, totals);                               \
-    hipLaunchKernelGGL((scatter_kernel<I_, K>), dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, src_v, dst_k, dst_v, (uint32_t)n, shift,  \
-                       mask, nbits, hist, nblocks, totals, n_dev);                                                                         \
+    hipLaunchKernelGGL((digit_histogram_kernel<I_, K, B_>), dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, (uint32_t)n, shift, mask, \
+                       hist, nblocks, n_dev, key_base);                                                                                    \
+    hipLaunchKernelGGL(scan_rows_kernel, dim3(B_), dim3(kSortThreads), 0, stream, hist, nblocks, totals);                                  \
+    hipLaunchKernelGGL((scatter_kernel<I_, K, B_>), dim3(nblocks), dim3(kSortThreads), 0, stream, src_k, src_v, dst_k, dst_v, (uint32_t)n, \
+                       shift, mask, nbits, hist, nblocks, totals, n_dev, key_base);                                                        \
+  } while (0)
+#define RG_SORT_PASS(I_)                     \
+  do {                                       \
+    if (bins == 512) RG_SORT_PASS_B(I_, 512); \
+    else RG_SORT_PASS_B(I_, 256);            \
   } while (0)
     if (items == 32) RG_SORT_PASS(32);
     else if (items == 16) RG_SORT_PASS(16);
     else RG_SORT_PASS(8);
+#undef RG_SORT_PASS_B
 #undef RG_SORT_PASS
     src_k = dst_k;
     src_v = dst_v;
@@ -340,6 +375,12 @@ static hipError_t radix_sort_pairs(void* temp, size_t temp_bytes, const K* keys_
 hipError_t radix_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
                                 uint32_t* vals_out, size_t n, int end_bit, hipStream_t stream, const uint32_t* n_dev) {
   return radix_sort_pairs<uint32_t>(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, end_bit, stream, n_dev);
+}
+// Sorts on bits [0, 27) of (key - key_base) in THREE passes of 9-bit digits (512 bins).  For keys that are the float bits of values in
+// [bits^-1(key_base), ...) the caller guarantees (key - key_base) < 2^27 for every item whose order matters; other items land anywhere.
+hipError_t radix_sort_pairs_u32_27(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
+                                   uint32_t* vals_out, size_t n, uint32_t key_base, hipStream_t stream) {
+  return radix_sort_pairs<uint32_t>(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 27, stream, nullptr, key_base, 9);
 }
 // the same sort over 16-bit keys (end_bit <= 16)
 hipError_t radix_sort_pairs_u16(void* temp, size_t temp_bytes, const uint16_t* keys_in, uint16_t* keys_out, const uint32_t* vals_in,

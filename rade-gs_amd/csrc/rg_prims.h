@@ -27,6 +27,8 @@ size_t sort_temp_bytes(size_t n);
 size_t scan_temp_bytes(size_t n);
 hipError_t radix_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
                                 uint32_t* vals_out, size_t n, int end_bit, hipStream_t stream, const uint32_t* n_dev = nullptr);
+hipError_t radix_sort_pairs_u32_27(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
+                                   uint32_t* vals_out, size_t n, uint32_t key_base, hipStream_t stream);
 hipError_t radix_sort_pairs_u16(void* temp, size_t temp_bytes, const uint16_t* keys_in, uint16_t* keys_out, const uint32_t* vals_in,
                                 uint32_t* vals_out, size_t n, int end_bit, hipStream_t stream, const uint32_t* n_dev = nullptr);
 hipError_t inclusive_scan_gather_u32(void* temp, size_t temp_bytes, const uint32_t* vals, const uint32_t* idx, uint32_t* out, size_t n,

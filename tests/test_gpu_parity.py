@@ -368,6 +368,19 @@ def test_handwritten_sort_matches_device_library():
     assert outs[0] == outs[1], outs
 
 
+def test_depths_beyond_the_three_pass_sort_window():
+    """The depth sort runs three 9-bit passes over (key - bits(0.2f)), valid while every visible depth is below 13 107; the per-Gaussian
+    kernel flags a key outside that window and the forward is redone with the four-pass sort (rg_launch.inc).  A scene scaled 3 000x
+    (depths 6 000 ... 30 000) takes that path on its first frame, the remembered 4-pass sort on the next; both must equal the oracle."""
+    import diff_gaussian_rasterization._C as C
+    s = make_scene(3000, 176, 144, sh_degree=1, mu_px=3.0, seed=77, kernel_size=0.0, require_coord=False, require_depth=True)
+    s = s._replace(means3D=s.means3D * 3000.0, scales=s.scales * 3000.0)
+    C.binning_stats(reset=True)
+    o, _ = check_forward(s)
+    check_backward(s, o, seed=77)
+    o, _ = check_forward(s)          # the (device, W, H) remembers: no redo any more, same result
+
+
 def test_very_long_tile_lists():
     """Every Gaussian covers the whole 48x32 image, so each of the 6 tiles lists all 9000 of them (hundreds of staging rounds per
     block, every block list as long as the tile list), twice in a row (exact sizes, then the speculative capacity)."""
