@@ -1431,6 +1431,9 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
         }
       } else {
         const float tot = wave_reduce_scatter<REC, true>(gs, lane);
+#if defined(RADEGS_EXP_NOATOMIC)      // timing experiment (scripts/build_alt.py): everything but the atomic (a.W < 0 never holds)
+        if (a.W < 0)
+#endif
         if (lane < (COORD ? 25 : 16)) unsafeAtomicAdd(a.acc + (size_t)gid * REC + lane, tot);
       }
     }
