@@ -24,10 +24,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(script_args, timeout=600):
+def _launch(script_args, timeout=600, nproc=1):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port())] + script_args
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
@@ -56,3 +56,21 @@ def test_bench_under_the_launcher_with_the_exchange_forced(exchange):
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["value"] > 0 and d["roofline"]["frac"] > 0
+
+
+def test_two_ranks_share_one_gpu_through_gloo(tmp_path):
+    """Two REAL ranks on the one GPU of the box (process group gloo: RCCL refuses two ranks per device): each renders its own view with
+    the HIP kernels, the factored exchange and the plain bucket run across the two processes, and the HIP rebuild kernel sums both
+    ranks' dL/dRGB rows -- against the batch mean every rank computes locally from both views (tests/gloo_gpu_worker.py)."""
+    out = tmp_path / "gloo"
+    p = _launch([os.path.join(ROOT, "tests", "gloo_gpu_worker.py"), str(out)], nproc=2)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    for rank in (0, 1):
+        res = json.load(open(f"{out}.{rank}"))
+        if not res["ok"] and "gloo" in res.get("error", "").lower() and "cuda" in res.get("error", "").lower():
+            pytest.skip("this torch build's gloo cannot move device tensors: " + res["error"][:200])
+        assert res["ok"], res
+        assert res["backend"] == "gloo" and res["world"] == 2
+        for mode in ("factored", "factored_early", "bucket"):
+            for k, v in res[mode].items():
+                assert v <= (2e-5 if k in ("dL_dsh", "dL_dopacity") else 1e-3), (rank, mode, k, v)
