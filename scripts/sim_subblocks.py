@@ -109,3 +109,23 @@ for Wn in (64, 128, 256, 512):
             for w0 in range(0, nt, Wn):
                 tot2 += max(int(((p4[i] >= w0) & (p4[i] < w0 + Wn)).sum()) for i in wv)
     print(f"        (same, if waves did not wait for each other: {tot2 / base:.3f}x)")
+
+# ---- a ring of `slots` half-size windows instead of barriers: a row may work in window w while no row is `slots` or more windows above it
+def ring(WN, slots=2):
+    tot = 0
+    for (nt, p8, _, _) in tiles:
+        lists = [p[::-1] for p in p8]          # rows walk back to front
+        ptr = [0] * 8
+        iters = [0, 0]
+        while any(ptr[r] < len(lists[r]) for r in range(8)):
+            wins = [lists[r][ptr[r]] // WN if ptr[r] < len(lists[r]) else -1 for r in range(8)]
+            slowest = max(wins)
+            adv = [wins[r] >= 0 and slowest - wins[r] < slots for r in range(8)]
+            for wv in (0, 1):
+                iters[wv] += any(adv[4 * wv:4 * wv + 4])
+            for r in range(8):
+                ptr[r] += adv[r]
+        tot += iters[0] + iters[1]
+    return tot / base
+for WN in (32, 64):
+    print(f"8x4 + per-tile workgroups + a ring of two windows of {WN} positions, no barriers: {ring(WN):.3f}x today's wave-iterations")
