@@ -80,7 +80,7 @@ n = (l8.size // 512) * 512
 it8 = np.sort(l8[:n].reshape(-1, 512), axis=1)[:, ::-1].reshape(-1, 4).max(1)
 print(f"today: wave-iterations per 128 px {it8.mean():.1f} (unsorted strips {l8[:n].reshape(-1, 4).max(1).mean():.1f}); lane utilisation {useful / (32 * it8.sum() * 4 / 4 * 4 / 4):.3f}" if False else
       f"today: wave-iterations per wave (128 px) {it8.mean():.1f}; slots {it8.sum() * 128:.3g}, useful pairs {useful:.3g}, lane utilisation {useful / (it8.sum() * 128):.3f}")
-base = it8.sum()
+base = it8.sum() * l8.size / n      # the neighbourhood sort covers whole groups of 512 blocks: scale to all blocks
 # new (a): per tile two waves; the 8 longest sub-blocks in one wave, the 8 shortest in the other; also balanced across a 64-tile neighbourhood
 per_tile = np.array([sorted((len(p) for p in t[2]), reverse=True) for t in tiles], float)   # [tiles, 16]
 it_a = per_tile[:, 0] + per_tile[:, 8]
@@ -88,7 +88,7 @@ print(f"new (a) whole-list accumulators, per-tile waves: wave-iterations per til
       f"lane utilisation {useful / (it_a.sum() * 128):.3f}")
 fl = l4[: (l4.size // 1024) * 1024]
 it_n = np.sort(fl.reshape(-1, 1024), axis=1)[:, ::-1].reshape(-1, 8).max(1)
-print(f"    (forward only: sub-blocks paired inside 64-tile neighbourhoods: {it_n.sum() / (it8[: it_n.size // 2 * 2].sum() if False else base * fl.size / l4.size):.3f}x)")
+print(f"    (forward only: sub-blocks paired inside 64-tile neighbourhoods: {it_n.sum() / (base * fl.size / l4.size):.3f}x)")
 # rounds of 16 entries: the forward / backward walk whole rounds only where a row still has entries; iterations are per entry (trip = min(16, nmax - 16 r)) -> same count
 for Wn in (64, 128, 256, 512):
     tot = 0.0
