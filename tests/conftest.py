@@ -51,8 +51,22 @@ def _build_test_infrastructure():
     """The oracle and the host-check harness are plain g++ builds (seconds)."""
     from oracle import oracle as orc
     from hostcheck import hostcheck as hc
-    orc.build()
-    hc.build()
+    # one builder at a time: under pytest-xdist every worker runs this fixture, and two compilers writing the same object file
+    # (or one linking while another compiles) fail each other
+    import fcntl
+    lock = open(os.path.join(ROOT, ".pytest_build.lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        orc.build()
+        hc.build()
+        _build_product()
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+    yield
+
+
+def _build_product():
     # The product never builds itself at import (a missing library is an error there).  The test-suite (re)builds it here,
     # in-tree, exactly as `__graft_entry__.build()` / `python rade-gs_amd/build.py` would: build.py is incremental (mtime
     # staleness), so an up-to-date tree costs nothing and an edited kernel is never tested through a stale library.
@@ -66,4 +80,3 @@ def _build_test_infrastructure():
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         mod.build(verbose=False)
-    yield
