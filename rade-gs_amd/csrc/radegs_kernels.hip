@@ -369,9 +369,20 @@ __device__ __forceinline__ bool five_sample(const float4 A, const float4 B, floa
   return used;
 }
 
+// Phase 2 walks the tile list again for every batch of 4 query points of a pixel and needs, per (pixel, entry), only WHETHER the
+// 5-sample test of phase 1 let the entry through ("used": the reference keeps those ids in a 2048-entry per-thread array,
+// forward.cu:1003,1121).  Round 1 replayed the test -- five specified exponentials per pair and pass; since round 4 phase 1 leaves one
+// bit per (pixel, entry) in wave-private LDS (64 bits per lane and batch of 64 entries, 12 batches = 6 KB) and phase 2 reads it:
+// the same decisions by construction, no exponential at all in phase 2.  Tiles with more than 768 entries replay as before.
+#if !defined(RADEGS_INTE_BATCHES)
+#define RADEGS_INTE_BATCHES 12   // 16: 5.26 ms on C2 with 4 M points, 12 / 10: 4.87 (LDS per wave decides the occupancy)
+#endif
+constexpr int kUsedBatches = RADEGS_INTE_BATCHES;   // (+ 3 KB of per-pixel staging for the point-major phase 2)
+
 __global__ void __launch_bounds__(64) integrate_kernel(const IntegrateArgs a) {
   __shared__ float4 lds_a[64 * 4];
   __shared__ float4 lds_i[64 * 2];
+  __shared__ unsigned long long lds_used[kUsedBatches * 64];
   const int item = xcd_band_remap(blockIdx.x, gridDim.x);
   const int tile = item >> 2, sub = item & 3;
   const int tile_x = tile % a.gx, tile_y = tile / a.gx;
@@ -408,6 +419,7 @@ __global__ void __launch_bounds__(64) integrate_kernel(const IntegrateArgs a) {
     }
     uint64_t rel = __ballot(rel_lane);
     __syncthreads();
+    unsigned long long used_bits = 0ull;
     while (rel != 0) {
       const int j = __builtin_ctzll(rel);
       rel &= rel - 1;
@@ -416,6 +428,7 @@ __global__ void __launch_bounds__(64) integrate_kernel(const IntegrateArgs a) {
       const float T = cT[0];
       FiveSample f;
       if (!five_sample(A, B, Cc.w, D.x, pixfx, pixfy, cT, f)) continue;
+      used_bits |= 1ull << j;
       if (f.pass0) {
         C0 += Cc.x * f.alpha0 * T; C1 += Cc.y * f.alpha0 * T; C2 += Cc.z * f.alpha0 * T;
       }
@@ -429,7 +442,9 @@ __global__ void __launch_bounds__(64) integrate_kernel(const IntegrateArgs a) {
       n_local += 1;
       if (n_local >= (uint32_t)kMaxContributors) done = true;  // the reference stops this pixel here (forward.cu:1121-1125)
     }
+    if ((base >> 6) < kUsedBatches) lds_used[(base >> 6) * 64 + lane] = used_bits;
   }
+  const bool cached = n <= kUsedBatches * 64;   // wave-uniform: every batch of this tile has its bits (else phase 2 replays the test)
   const float T = cT[0];
   float col0 = 0.f, col1 = 0.f, col2 = 0.f;
   if (inside) {
@@ -446,6 +461,112 @@ __global__ void __launch_bounds__(64) integrate_kernel(const IntegrateArgs a) {
     cur = pix == 0 ? 0u : a.pix_incl[pix - 1];
     pe = a.pix_incl[pix];
     a.out9[8 * HW + pix] = (float)(pe - cur);
+  }
+  if (cached) {
+    // ---- point-major phase 2 (round 4): one query point per LANE.  The per-pixel form below gives every pixel-lane four point slots
+    // per walk of the list; a pixel holds 1.6 points on average (C2, 4 M points) and an entry is used by a quarter of a strip's pixels,
+    // so ~one lane-slot in ten does work.  Here the strip's points (sorted by pixel: four runs of pt_sorted) are dealt to the lanes 64 at
+    // a time; a point-lane reads ITS pixel's used bits and per-pixel results from LDS and carries one point through the walk.
+    __shared__ float lds_pix[64 * 8];      // per pixel of the strip: colour (3), median plane (depth, px, py, mx, my)
+    __shared__ uint32_t lds_off[64 + 1];   // exclusive scan of the pixels' point counts
+    __shared__ uint32_t lds_first[64];     // first index of the pixel's points in pt_sorted
+    __shared__ uint32_t lds_last[64];      // the pixel's last contributor (bound of its walk)
+    const uint32_t cnt = pe - cur;
+    uint32_t incl = cnt;                   // inclusive wave scan of the counts
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = (uint32_t)__shfl_up((int)incl, d);
+      if (lane >= d) incl += y;
+    }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    __syncthreads();
+    lds_off[lane] = incl - cnt;
+    if (lane == 63) lds_off[64] = total;
+    lds_first[lane] = cur;
+    lds_last[lane] = last_c;
+    lds_pix[lane * 8 + 0] = col0; lds_pix[lane * 8 + 1] = col1; lds_pix[lane * 8 + 2] = col2;
+    lds_pix[lane * 8 + 3] = mid_dc; lds_pix[lane * 8 + 4] = mid_px; lds_pix[lane * 8 + 5] = mid_py;
+    lds_pix[lane * 8 + 6] = mid_mx; lds_pix[lane * 8 + 7] = mid_my;
+    __syncthreads();
+    for (uint32_t r0 = 0; r0 < total; r0 += 64) {
+      const uint32_t q = r0 + (uint32_t)lane;
+      const bool have = q < total;
+      // the pixel this point belongs to: the last p with off[p] <= q (binary search over the 64 offsets)
+      int p = 0;
+      if (have) {
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+          if (lds_off[p + step] <= q) p += step;
+      }
+      uint32_t pid1 = 0;
+      float qx1 = 0.f, qy1 = 0.f, qd1 = 0.f, pa1 = 0.f, pT1 = 1.f;
+      if (have) {
+        pid1 = a.pt_sorted[lds_first[p] + (q - lds_off[p])];
+        const float2 qq = a.p2d[pid1];
+        qx1 = qq.x; qy1 = qq.y; qd1 = a.pdepth[pid1];
+      }
+      const uint32_t my_last = have ? lds_last[p] : 0u;
+      for (int base = 0; base < n; base += 64) {
+        if (__all((uint32_t)base >= my_last)) break;
+        __syncthreads();
+        const int k = base + lane;
+        bool rel_lane = false;
+        if (k < n) {
+          const uint32_t g = a.point_list[range.x + k];
+          const float4* src = a.splat_a + 4 * (size_t)g;
+          const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+          lds_a[lane * 4 + 0] = q0; lds_a[lane * 4 + 1] = q1; lds_a[lane * 4 + 2] = q2; lds_a[lane * 4 + 3] = q3;
+          const float4* si = a.inte_rec + 2 * (size_t)g;
+          lds_i[lane * 2 + 0] = si[0]; lds_i[lane * 2 + 1] = si[1];
+          rel_lane = entry_may_touch(q0, q1, reg_x0, reg_x1, reg_y0, reg_y1);
+        }
+        uint64_t rel = __ballot(rel_lane);
+        __syncthreads();
+        const unsigned long long my_bits = have ? lds_used[(base >> 6) * 64 + p] : 0ull;
+        while (rel != 0) {
+          const int j = __builtin_ctzll(rel);
+          rel &= rel - 1;
+          const bool mine = ((my_bits >> j) & 1ull) != 0ull;     // phase 1's decision for (this point's pixel, entry)
+          if (!__any(mine)) continue;
+          if (!mine) continue;
+          const float4 A = lds_a[j * 4 + 0], B = lds_a[j * 4 + 1], Cc = lds_a[j * 4 + 2], D = lds_a[j * 4 + 3];
+          const float4 I0 = lds_i[j * 2 + 0], I1 = lds_i[j * 2 + 1];
+          const m3 inv = mk33(I0.x, I0.y, I0.z, I0.y, I0.w, I1.x, I0.z, I1.x, I1.y);
+          const bool cond = I1.z != 0.0f;
+          const float dx = A.x - qx1, dy = A.y - qy1;
+          const float depth = B.w + (Cc.w * dx + D.x * dy);
+          float alpha;
+          if (cond) {
+            const v3 du = mk3(dx, dy, B.w - fminf(qd1, depth));
+            const float power = -0.5f * dot(du, mul(inv, du));
+            alpha = fminf(0.99f, B.y * exp_spec(fminf(power, 80.0f)));
+          } else if (qd1 < depth) {
+            alpha = 0.f;
+          } else {
+            const v3 du = mk3(dx, dy, B.w);
+            const float power = -0.5f * dot(du, mul(inv, du));
+            alpha = fminf(0.99f, B.y * exp_spec(fminf(power, 80.0f)));
+          }
+          if (alpha < 1.0f / 255.0f) continue;
+          const float test_T = pT1 * (1 - alpha);
+          pa1 += alpha * pT1;
+          pT1 = test_T;
+        }
+      }
+      if (have) {
+        const size_t qi = pid1;
+        const float* pp = lds_pix + p * 8;
+        a.out_alpha_integrated[qi] = pa1;
+        a.out_color_integrated[3 * qi] = pp[0]; a.out_color_integrated[3 * qi + 1] = pp[1]; a.out_color_integrated[3 * qi + 2] = pp[2];
+        a.out_coordinate2d[2 * qi] = qx1; a.out_coordinate2d[2 * qi + 1] = qy1;
+        if (qd1 > 0) {
+          const float dx = pp[6] - qx1, dy = pp[7] - qy1;
+          const float depth = pp[3] + (pp[4] * dx + pp[5] * dy);
+          a.out_sdf[qi] = depth - qd1;
+        }
+      }
+    }
+    return;
   }
   while (__any(cur < pe)) {
     const int np = (int)min((uint32_t)kPointsPerPass, pe - cur);
@@ -478,13 +599,20 @@ __global__ void __launch_bounds__(64) integrate_kernel(const IntegrateArgs a) {
       }
       uint64_t rel = __ballot(rel_lane);
       __syncthreads();
+      const unsigned long long my_bits = cached ? lds_used[(base >> 6) * 64 + lane] : 0ull;
       while (rel != 0) {
         const int j = __builtin_ctzll(rel);
         rel &= rel - 1;
-        if ((uint32_t)(base + j + 1) > my_last) continue;
+        if (cached) {                                   // phase 1's decision for this (pixel, entry)
+          const bool mine = np > 0 && ((my_bits >> j) & 1ull) != 0ull;
+          if (!__any(mine)) continue;
+          if (!mine) continue;
+        } else if ((uint32_t)(base + j + 1) > my_last) continue;
         const float4 A = lds_a[j * 4 + 0], B = lds_a[j * 4 + 1], Cc = lds_a[j * 4 + 2], D = lds_a[j * 4 + 3];
-        FiveSample f;
-        if (!five_sample(A, B, Cc.w, D.x, pixfx, pixfy, rT, f)) continue;
+        if (!cached) {
+          FiveSample f;
+          if (!five_sample(A, B, Cc.w, D.x, pixfx, pixfy, rT, f)) continue;
+        }
         const float4 I0 = lds_i[j * 2 + 0], I1 = lds_i[j * 2 + 1];
         const m3 inv = mk33(I0.x, I0.y, I0.z, I0.y, I0.w, I1.x, I0.z, I1.x, I1.y);
         const bool cond = I1.z != 0.0f;
