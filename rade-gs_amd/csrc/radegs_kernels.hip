@@ -78,10 +78,13 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(const PreFwdArgs a)
   const Camera cam = load_camera(a.cam);
   SplatFwd s;
   const float* m = a.means3D + 3 * (size_t)idx;
-  preprocess_fwd<INTE>(mk3(m[0], m[1], m[2]), a.scales ? a.scales + 3 * (size_t)idx : nullptr,
-                 a.rotations ? a.rotations + 4 * (size_t)idx : nullptr, a.cov3D_precomp ? a.cov3D_precomp + 6 * (size_t)idx : nullptr,
-                 a.opacities[idx], a.D, a.shs ? a.shs + (size_t)idx * a.M * 3 : nullptr,
-                 a.colors_precomp ? a.colors_precomp + 3 * (size_t)idx : nullptr, cam, s);
+  const v3 p_orig = mk3(m[0], m[1], m[2]);
+  const float* sh = a.shs ? a.shs + (size_t)idx * a.M * 3 : nullptr;
+  const float* color_in = a.colors_precomp ? a.colors_precomp + 3 * (size_t)idx : nullptr;
+  const float* scale3 = a.scales ? a.scales + 3 * (size_t)idx : nullptr;
+  const float* quat4 = a.rotations ? a.rotations + 4 * (size_t)idx : nullptr;
+  const float* cov_in = a.cov3D_precomp ? a.cov3D_precomp + 6 * (size_t)idx : nullptr;
+  preprocess_fwd<INTE>(p_orig, scale3, quat4, cov_in, a.opacities[idx], a.D, sh, color_in, cam, s);
   a.radii[idx] = s.radius;
   a.tiles_touched[idx] = (uint32_t)s.tiles;
   a.rect[idx] = s.radius > 0 ? s.rect : 0u;
@@ -1580,6 +1583,7 @@ struct PreBwdArgs {
   int opacity_grad_intended;  // RadegsBwdArgs::opacity_grad_intended (include/radegs.h)
   int drgb_done;              // dL_drgb_clamped was already written by drgb_clamped_kernel (RadegsBwdArgs::drgb_ready)
   int acc_final;              // the records hold the reference's FINAL per-Gaussian sums (constant factors applied): radegs_backward_from_sums
+  int vec_slab;               // the SH slab moves in 16-byte pieces (3M % 4 == 0, 3M <= 48, shs and dL_dsh 16-byte aligned)
 };
 
 // dL/dRGB with the SH clamp mask applied, straight from the blend backward's sums (the first three floats of every accumulator
@@ -1619,6 +1623,16 @@ __device__ __forceinline__ void slab_copy(float* slab, float* gmem, int nrows, i
   }
 }
 
+// Memory-level parallelism (round 4).  The kernel moves ~670 B per Gaussian and computes for ~5 000 instructions at 3 waves per SIMD:
+// what it cannot afford is a chain of dependent memory latencies.  The first version copied the slab with 4-byte loads in a loop the
+// compiler unrolled by 8 -- 2 KB in flight per wave, six full latencies per block one after the other -- and only then, behind the
+// barrier and the visibility test, asked for the Gaussian's own records: ~6 MB in flight on the whole chip, which at ~1.5 us of loaded
+// latency is the 3.5 TB/s it ran at.  Now EVERY global read of a block is issued before anything waits: the slab as 12 x 16 bytes per
+// thread (rows of 3M floats with 3M % 4 == 0 and 16-byte aligned tensors, i.e. SH degree 3 and 1; other shapes keep the word loop),
+// the accumulator record, mean, scale, rotation and flags of the thread's Gaussian (for invisible ones too: the record is there and
+// reading it costs less than waiting for `radii` first).  LDS side: row stride 3M + 1 words, so a 16-byte piece goes in as four words;
+// neighbouring lanes are 4 words apart and rows shift by one word, which keeps the 64 lanes of a store on different banks.
+constexpr int kSlabVecs = 12;   // 16-byte pieces per thread: 128 rows x 48 floats / 128 threads
 __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const PreBwdArgs a) {
   extern __shared__ float sh_slab[];  // [128][3M+1]
   const int tid = threadIdx.x;
@@ -1627,14 +1641,58 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
   const int nrows = min(kPreBwdThreads, a.P - base);
   const int rowf = a.M * 3, stride = rowf + 1;
   const bool have_sh = a.shs != nullptr;
-  if (have_sh) {
-    slab_copy<true>(sh_slab, const_cast<float*>(a.shs) + (size_t)base * rowf, nrows, rowf, tid);
-    __syncthreads();
+  const bool vec = have_sh && a.vec_slab != 0;   // host: rowf % 4 == 0, rowf <= 4 * kSlabVecs, shs and dL_dsh 16-byte aligned
+  const int rowf4 = rowf >> 2, n4 = nrows * rowf4;
+  const uint32_t magic4 = vec ? 0xFFFFFFFFu / (uint32_t)rowf4 + 1u : 0u;   // floor(e / rowf4) == mulhi(e, magic4), as in slab_copy
+
+  // ---- every global read of the block ----
+  float4 v[kSlabVecs];
+  if (vec) {
+    const float4* g4 = reinterpret_cast<const float4*>(a.shs + (size_t)base * rowf);
+#pragma unroll
+    for (int k = 0; k < kSlabVecs; k++) {
+      const int e4 = tid + k * kPreBwdThreads;
+      v[k] = e4 < n4 ? g4[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
-  if (idx < a.P) {
-    const size_t i = (size_t)idx;
+  const bool live = idx < a.P;
+  const size_t i = live ? (size_t)idx : 0;
+  const bool has_sr = a.scales != nullptr;
+  int radius = 0;
+  unsigned cflags = 0;
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0, rq = r0;
+  float r6 = 0.f, m0 = 0.f, m1 = 0.f, m2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  if (live) {
+    radius = a.radii[idx];
+    const float4* r = reinterpret_cast<const float4*>(a.acc + i * a.rec);
+    r0 = r[0]; r1 = r[1]; r2 = r[2]; r3 = r[3];
+    if (a.rec == 32) { r4 = r[4]; r5 = r[5]; r6 = r[6].x; }
+    m0 = a.means3D[3 * i]; m1 = a.means3D[3 * i + 1]; m2 = a.means3D[3 * i + 2];
+    if (has_sr) {
+      s0 = a.scales[3 * i]; s1 = a.scales[3 * i + 1]; s2 = a.scales[3 * i + 2];
+      rq = *reinterpret_cast<const float4*>(a.rotations + 4 * i);
+    }
+    cflags = (unsigned)a.clamped[idx];   // bits 0..2: SH clamp flags (written for visible Gaussians only; unused otherwise)
+  }
+
+  if (vec) {
+#pragma unroll
+    for (int k = 0; k < kSlabVecs; k++) {
+      const int e4 = tid + k * kPreBwdThreads;
+      if (e4 < n4) {
+        const int g = (int)__umulhi((uint32_t)e4, magic4), c = (e4 - g * rowf4) << 2;
+        float* d = sh_slab + g * stride + c;
+        d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+      }
+    }
+  } else if (have_sh) {
+    slab_copy<true>(sh_slab, const_cast<float*>(a.shs) + (size_t)base * rowf, nrows, rowf, tid);
+  }
+  if (have_sh) __syncthreads();
+
+  if (live) {
     float* row = have_sh ? sh_slab + tid * stride : nullptr;
-    if (!(a.radii[idx] > 0)) {  // invisible: every returned row is zero (rasterize_points.cu:180-193)
+    if (!(radius > 0)) {  // invisible: every returned row is zero (rasterize_points.cu:180-193)
 #pragma unroll
       for (int c = 0; c < 3; c++) { a.dL_dmean2D[3 * i + c] = 0; a.dL_dcolor[3 * i + c] = 0; a.dL_dmean3D[3 * i + c] = 0; a.dL_dscale[3 * i + c] = 0; }
       a.dL_dopacity[i] = 0;
@@ -1647,23 +1705,17 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
     } else {
       const Camera cam = load_camera(a.cam);
       SplatAcc acc;
-      {
-        const float4* r = reinterpret_cast<const float4*>(a.acc + i * a.rec);
-        const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
-        acc.dcolor[0] = r0.x; acc.dcolor[1] = r0.y; acc.dcolor[2] = r0.z; acc.dts = r0.w;
-        acc.drp[0] = r1.x; acc.drp[1] = r1.y; acc.dnrm[0] = r1.z; acc.dnrm[1] = r1.w;
-        acc.dnrm[2] = r2.x; acc.dmean2D[0] = r2.y; acc.dmean2D[1] = r2.z; acc.dmean2D[2] = r2.w;
-        acc.dconic[0] = r3.x; acc.dconic[1] = r3.y; acc.dconic[2] = r3.z; acc.dop = r3.w;
-        if (a.rec == 32) {
-          const float4 r4 = r[4], r5 = r[5];
-          const float r6 = r[6].x;
-          acc.dvp[0] = r4.x; acc.dvp[1] = r4.y; acc.dvp[2] = r4.z; acc.dcp[0] = r4.w;
-          acc.dcp[1] = r5.x; acc.dcp[2] = r5.y; acc.dcp[3] = r5.z; acc.dcp[4] = r5.w; acc.dcp[5] = r6;
-        } else {
-          acc.dvp[0] = acc.dvp[1] = acc.dvp[2] = 0.f;
+      acc.dcolor[0] = r0.x; acc.dcolor[1] = r0.y; acc.dcolor[2] = r0.z; acc.dts = r0.w;
+      acc.drp[0] = r1.x; acc.drp[1] = r1.y; acc.dnrm[0] = r1.z; acc.dnrm[1] = r1.w;
+      acc.dnrm[2] = r2.x; acc.dmean2D[0] = r2.y; acc.dmean2D[1] = r2.z; acc.dmean2D[2] = r2.w;
+      acc.dconic[0] = r3.x; acc.dconic[1] = r3.y; acc.dconic[2] = r3.z; acc.dop = r3.w;
+      if (a.rec == 32) {
+        acc.dvp[0] = r4.x; acc.dvp[1] = r4.y; acc.dvp[2] = r4.z; acc.dcp[0] = r4.w;
+        acc.dcp[1] = r5.x; acc.dcp[2] = r5.y; acc.dcp[3] = r5.z; acc.dcp[4] = r5.w; acc.dcp[5] = r6;
+      } else {
+        acc.dvp[0] = acc.dvp[1] = acc.dvp[2] = 0.f;
 #pragma unroll
-          for (int c = 0; c < 6; c++) acc.dcp[c] = 0.f;
-        }
+        for (int c = 0; c < 6; c++) acc.dcp[c] = 0.f;
       }
       // constant factors the blend backward left out of its sums (linear, so they commute with the sum):
       // 1/focal on the plane gradients (backward.cu:917-922,939-940), W/2 and H/2 on mean2D (:1002-1003)
@@ -1674,14 +1726,7 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
         for (int c = 0; c < 3; c++) { acc.dcp[2 * c] *= ifx; acc.dcp[2 * c + 1] *= ify; }
         acc.dmean2D[0] *= 0.5f * cam.W; acc.dmean2D[1] *= 0.5f * cam.H;
       }
-      const float* m = a.means3D + 3 * i;
-      float sc3[3], rq4[4];
-      const bool has_sr = a.scales != nullptr;
-      if (has_sr) {
-        sc3[0] = a.scales[3 * i]; sc3[1] = a.scales[3 * i + 1]; sc3[2] = a.scales[3 * i + 2];
-        const float4 q = *reinterpret_cast<const float4*>(a.rotations + 4 * i);
-        rq4[0] = q.x; rq4[1] = q.y; rq4[2] = q.z; rq4[3] = q.w;
-      }
+      float sc3[3] = {s0, s1, s2}, rq4[4] = {rq.x, rq.y, rq.z, rq.w};
       float cov[6];
       if (a.cov3D_precomp) {
 #pragma unroll
@@ -1698,8 +1743,7 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
       }
       SplatBwd o;
       o.dscale[0] = o.dscale[1] = o.dscale[2] = 0; o.drot[0] = o.drot[1] = o.drot[2] = o.drot[3] = 0;
-      const unsigned cflags = (unsigned)a.clamped[idx];   // bits 0..2: SH clamp flags
-      preprocess_bwd(mk3(m[0], m[1], m[2]), has_sr ? sc3 : nullptr, has_sr ? rq4 : nullptr, cov, op_combined, a.D, row,
+      preprocess_bwd(mk3(m0, m1, m2), has_sr ? sc3 : nullptr, has_sr ? rq4 : nullptr, cov, op_combined, a.D, row,
                      cflags & 7u, cam, acc, row, o);
 #pragma unroll
       for (int c = 0; c < 3; c++) {
@@ -1710,7 +1754,7 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
       }
       a.dL_dopacity[i] = o.dopacity;
       if (a.dL_drgb_clamped && !a.drgb_done) {
-        const unsigned cl = (unsigned)a.clamped[idx] & 7u;
+        const unsigned cl = cflags & 7u;
 #pragma unroll
         for (int c = 0; c < 3; c++) a.dL_drgb_clamped[3 * i + c] = acc.dcolor[c] * (((cl >> c) & 1u) ? 0.f : 1.f);
       }
@@ -1721,7 +1765,20 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
   }
   if (have_sh && a.dL_dsh) {
     __syncthreads();
-    slab_copy<false>(sh_slab, a.dL_dsh + (size_t)base * rowf, nrows, rowf, tid);
+    if (vec) {
+      float4* g4 = reinterpret_cast<float4*>(a.dL_dsh + (size_t)base * rowf);
+#pragma unroll
+      for (int k = 0; k < kSlabVecs; k++) {
+        const int e4 = tid + k * kPreBwdThreads;
+        if (e4 < n4) {
+          const int g = (int)__umulhi((uint32_t)e4, magic4), c = (e4 - g * rowf4) << 2;
+          const float* d = sh_slab + g * stride + c;
+          g4[e4] = make_float4(d[0], d[1], d[2], d[3]);
+        }
+      }
+    } else {
+      slab_copy<false>(sh_slab, a.dL_dsh + (size_t)base * rowf, nrows, rowf, tid);
+    }
   }
 }
 
