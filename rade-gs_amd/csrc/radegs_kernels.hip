@@ -1606,7 +1606,10 @@ __global__ void __launch_bounds__(256) drgb_clamped_kernel(int P, const int* __r
 // written by one thread each they would be 64 different cache lines per instruction.  The block therefore
 // moves its contiguous 128-row slab with coalesced accesses through LDS (row stride 3M+1 words: odd, so the
 // per-thread row walks are bank-conflict free); sh and dL/dsh share the slab (sh_bwd's access order allows it).
-constexpr int kPreBwdThreads = 128;
+#ifndef RADEGS_PREBWD_THREADS
+#define RADEGS_PREBWD_THREADS 128   // measured, round 4 (scripts/build_alt.py): see DESIGN.md 4.5
+#endif
+constexpr int kPreBwdThreads = RADEGS_PREBWD_THREADS;
 // Copies a block's contiguous [nrows][rowf] slab between global memory and the LDS slab of row stride rowf + 1, 128 consecutive
 // words per step.  (row, column) of word e come from a multiply-high by the reciprocal of the run-time row length (exact for
 // the slab's few thousand words): a true division per word cost more than everything else the kernel does, and carrying
