@@ -264,6 +264,21 @@ def test_merged_stream_backward(coord, depth, merged, wn, monkeypatch):
     check_backward(s, o, seed=64)
 
 
+if __import__("os").environ.get("RADEGS_TEST_UNVERIFIED") == "1":
+    # blend_bwd_streams_kernel<coord, ., ., LINEWISE> was written after round 4's GPU budget was spent: it is not a default,
+    # and its test only exists on request until it has passed on a GPU once
+    @pytest.mark.parametrize("depth", [False, True])
+    def test_linewise_coord_stream_backward(depth, monkeypatch):
+        """coord-map modes, unmerged stream backward with one atomic instruction per 64-byte line of the record (RADEGS_BWD_LINEWISE=1)"""
+        monkeypatch.setenv("RADEGS_STREAMS", "1")
+        monkeypatch.setenv("RADEGS_BWD_MERGED", "0")
+        monkeypatch.setenv("RADEGS_BWD_LINEWISE", "1")
+        s = make_scene(5000, 203, 131, sh_degree=2, mu_px=5.0, seed=64, kernel_size=0.1, require_coord=True, require_depth=depth,
+                       pose="random", bg=(0.3, 0.1, 0.7))
+        o, _ = check_forward(s)
+        check_backward(s, o, seed=64)
+
+
 def test_entry_streams_heavy_overdraw_termination_and_ragged_image(monkeypatch):
     """Forced entry streams on big splats: lists of hundreds of entries per block, rows of pixels that terminate early (their
     block stops consuming its list) next to rows that do not, partial rounds, tail tiles of a ragged image."""
