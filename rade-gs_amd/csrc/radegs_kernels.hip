@@ -1283,7 +1283,12 @@ __device__ __forceinline__ void row_reduce_scatter(float (&v)[N], int lane) {
   }
 }
 
-template <bool COORD, bool DEPTH, int PPL, int NG = 0>
+// LINEWISE (coord map, four streams; RADEGS_BWD_LINEWISE=1 -- written at the end of round 4, not yet run on a GPU, off by default): the
+// generic 32-component reduce-scatter leaves lane l with components 2l, 2l + 1, so both atomic instructions of a (row, entry) write into
+// BOTH 64-byte lines of the record -- four line updates instead of two, which is what "with the coord map's 32-float records even four
+// streams saturate the atomic units" (rg_launch.inc: auto_streams) was measured on.  Two 16-component reductions give lane l the
+// components l and 16 + l: one line per instruction.
+template <bool COORD, bool DEPTH, int PPL, int NG = 0, bool LINEWISE = false>
 __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 2 : (NG ? 4 : 5)))) blend_bwd_packed_kernel(const BlendBwdArgs a) {
   constexpr bool GROUPED = NG != 0;
   static_assert(PPL == 2 || PPL == 4, "pairs of pixels per lane");
@@ -1552,14 +1557,30 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
       if constexpr (GROUPED) {
         // every row reduces ITS entry's 16 (32) components over its 16 lanes; rows nobody contributed in skip the update
         constexpr int GL = GroupShape<NG>::LANES, PER = REC / GL;   // components left per lane: comps l*PER .. l*PER+PER-1
-        row_reduce_scatter<REC, GL>(gs, lane);
         const bool grp_live = ((contrib_mask >> (lane & ~(GL - 1))) & ((1ull << GL) - 1ull)) != 0;
         const int l = lane & (GL - 1);
-        if (grp_live) {
+        if constexpr (COORD && LINEWISE && GL == 16) {
+          row_reduce_scatter<16, 16>(*reinterpret_cast<float (*)[16]>(gs), lane);        // lane l: component l
+          row_reduce_scatter<16, 16>(*reinterpret_cast<float (*)[16]>(gs + 16), lane);   // lane l: component 16 + l
+          if (grp_live) {
+            unsafeAtomicAdd(a.acc + (size_t)gid * REC + l, gs[0]);
+            if (l < 9) unsafeAtomicAdd(a.acc + (size_t)gid * REC + 16 + l, gs[16]);
+          }
+        } else {
+          row_reduce_scatter<REC, GL>(gs, lane);
+          if (grp_live) {
 #pragma unroll
-          for (int i = 0; i < PER; i++)
-            if (l * PER + i < (COORD ? 25 : 16)) unsafeAtomicAdd(a.acc + (size_t)gid * REC + l * PER + i, gs[i]);
+            for (int i = 0; i < PER; i++)
+              if (l * PER + i < (COORD ? 25 : 16)) unsafeAtomicAdd(a.acc + (size_t)gid * REC + l * PER + i, gs[i]);
+          }
         }
+      } else if constexpr (COORD && LINEWISE) {
+        // (prepared with the variant above, not yet run on a GPU)  The 32-component wave reduction opens with a cross-row stage: 16
+        // ds_bpermute + 32 selects per entry (23 bpermutes in all).  Two 16-component reductions stay inside the DPP rows for four
+        // stages each and cross the rows only with their single result: 30 DPP adds + 4 bpermutes.  Rows 0 and 1 then carry the two lines.
+        const float lo = wave_reduce_scatter<16, true>(*reinterpret_cast<float (*)[16]>(gs), lane);
+        const float hi = wave_reduce_scatter<16, true>(*reinterpret_cast<float (*)[16]>(gs + 16), lane);
+        if (lane < 25) unsafeAtomicAdd(a.acc + (size_t)gid * REC + lane, lane < 16 ? lo : hi);
       } else {
         const float tot = wave_reduce_scatter<REC, true>(gs, lane);
 #if defined(RADEGS_EXP_NOATOMIC)      // timing experiment (scripts/build_alt.py): everything but the atomic (a.W < 0 never holds)

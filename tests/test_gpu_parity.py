@@ -278,6 +278,19 @@ if __import__("os").environ.get("RADEGS_TEST_UNVERIFIED") == "1":
         o, _ = check_forward(s)
         check_backward(s, o, seed=64)
 
+    @pytest.mark.parametrize("grouped", [4, 0])
+    @pytest.mark.parametrize("depth", [False, True])
+    def test_linewise_coord_tile_wide_backward(depth, grouped, monkeypatch):
+        """coord-map modes, tile-wide backward: four streams per wave with line-wise atomics (RADEGS_GROUPED_BWD=4), one stream with the
+        reduction in two 16-component halves (0); both behind RADEGS_BWD_LINEWISE=1"""
+        monkeypatch.setenv("RADEGS_STREAMS", "0")
+        monkeypatch.setenv("RADEGS_GROUPED_BWD", str(grouped))
+        monkeypatch.setenv("RADEGS_BWD_LINEWISE", "1")
+        s = make_scene(4000, 203, 131, sh_degree=2, mu_px=3.0, seed=61, kernel_size=0.1, require_coord=True, require_depth=depth,
+                       pose="random", bg=(0.3, 0.1, 0.7))
+        o, _ = check_forward(s)
+        check_backward(s, o, seed=61)
+
 
 def test_entry_streams_heavy_overdraw_termination_and_ragged_image(monkeypatch):
     """Forced entry streams on big splats: lists of hundreds of entries per block, rows of pixels that terminate early (their
