@@ -66,7 +66,7 @@ def binning_bytes_moved(P, R, tiles, streams):
     the first pass) and writes both) = 76 P; gather-scan 20 P; emission reads 12 P (index, offset, packed rectangle) + the 64-B record
     of every visible splat when block masks are computed, writes 6 R (16-bit tile key + value; 8 R above 65 536 tiles); tile sort
     2 passes x 14 R (20 R with 32-bit keys); ranges 2 R + 8 tiles."""
-    k = 2 if tiles <= 65535 and os.environ.get("RADEGS_KEY16", "1") != "0" else 4
+    k = 2 if tiles <= 65535 else 4
     return 76 * P + 20 * P + 12 * P + (4 + k) * R + 2 * (8 + 3 * k) * R + k * R + 8 * tiles + (64 * P if streams else 0)
 
 
@@ -86,6 +86,9 @@ def main():
                     help="'forward': the step is the forward alone under no_grad -- what the reference's inference callers execute "
                          "(render.py:32, mesh_extract.py:56: render() with both maps on; use with --flags both); metric Mimages/s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the legs that run AFTER (outside) the timed region at N=1 on the headline config: one short bench line each for "
+                         "the other BASELINE configs with a GPU (C3, C4, C5 -> `other_configs`) and one full training iteration (`train_iter_ms`)")
     ap.add_argument("--force-allreduce", action="store_true", help="run the RCCL gradient exchange even at world size 1 (path check)")
     ap.add_argument("--exchange", choices=("factored", "allreduce"), default="factored",
                     help="N>1 gradient exchange: 'factored' all-gathers the 12-B dL/dRGB rows and rebuilds the SH gradient locally "
@@ -308,10 +311,44 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_cpu, cfg["seed"])
+        if (world == 1 and not launched and not args.no_other_configs and args.config == "C2" and args.flags == "config" and args.mode == "train"
+                and not args.points and not args.mu_px):
+            del s, g, cams                      # the other configs run in child processes of their own: give the memory back first
+            torch.cuda.empty_cache()
+            out["other_configs"], out["train_iter_ms"] = other_configs_and_train_iter()
         print(json.dumps(out), flush=True)
     if launched:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def other_configs_and_train_iter():
+    """Outside the timed region, after it: the other BASELINE configs that run on one GPU, each as a child `bench.py --config Cx`
+    (10 steps), reduced to {ms_per_step, value, roofline kernel and fraction}; and scripts/gpu_train_iter.py's full training iteration
+    (3D filter -> rasterizer -> L1/SSIM + normal loss -> backward -> Adam at C2 scale).  A leg that fails or takes more than 150 s
+    reports its error instead of a number -- the headline line is printed either way."""
+    import re
+    import subprocess
+    res = {}
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-other-configs"]
+    legs = [("C3", ["--config", "C3"]), ("C4", ["--config", "C4"]), ("C5", ["--config", "C5"]), ("C2_both_maps", ["--flags", "both"]),
+            ("C2_both_maps_forward_only", ["--flags", "both", "--mode", "forward"])]
+    for name, extra in legs:
+        try:
+            p = subprocess.run(base + extra, capture_output=True, text=True, timeout=150)
+            d = json.loads(p.stdout.strip().splitlines()[-1])
+            res[name] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "roofline_kernel": d["roofline"]["kernel"],
+                         "roofline_frac": d["roofline"]["frac"], "blend": d["pairs"]["formulation"], "num_rendered": d["config"]["num_rendered"]}
+        except Exception as ex:   # noqa: BLE001 -- a reporting leg must not take the headline line with it
+            res[name] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
+    train = None
+    try:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_train_iter.py")], capture_output=True, text=True, timeout=150)
+        m = re.search(r"full training iteration.*?:\s*([0-9.]+) ms", p.stdout)
+        train = float(m.group(1)) if m else None
+    except Exception:   # noqa: BLE001
+        train = None
+    return res, train
 
 
 def pair_evaluations(C, s, last_state, coord):
@@ -327,8 +364,7 @@ def pair_evaluations(C, s, last_state, coord):
     pad[:H, :W] = ncon
     reach = pad.view(pad.shape[0] // 16, 16, pad.shape[1] // 16, 16).amax(dim=(1, 3)).to(torch.int64)   # per tile: last entry any pixel blended
     tilewide = int(256 * reach.sum().item())
-    env = os.environ.get("RADEGS_STREAMS")
-    streams = (R < 24 * P and (not coord or (R < 1024 * tiles and os.environ.get("RADEGS_STREAMS_COORD", "1") != "0"))) if env is None else env != "0"
+    streams = bool(C.last_forward_used_streams())   # the library's own decision for the forward that left this state (include/radegs.h)
     if streams:
         cons = C.debug_export("blk_consumed", torch.int32, 8 * tiles, P, R, W, H, coord, geom, binning, img).to(torch.int64)
         return {"formulation": "entry streams (8x4-pixel blocks)", "evaluated": int(32 * cons.sum().item()), "tilewide": tilewide}

@@ -45,6 +45,8 @@ extern "C" {
 #define RADEGS_ERR_ALLOC (-2)
 #define RADEGS_ERR_HIP (-3)
 #define RADEGS_ERR_NO_DEVICE (-4)
+#define RADEGS_ERR_STATE (-5)   /* an earlier radegs_backward on this thread and device was handed an image buffer that does not hold what
+                                   its forward wrote (reused or overwritten state): that call's gradients are invalid */
 
 /* Allocator callback: return a DEVICE pointer to at least `nbytes` bytes (256-B aligned), or
  * NULL on failure.  Mirrors the resize lambdas of DGR/rasterize_points.cu:27-33. */
@@ -82,8 +84,9 @@ typedef struct RadegsFwdArgs {
 /* Returns num_rendered (>= 0) or a negative RADEGS_ERR_*.
  * Host synchronisation: the FIRST call for a (device, width, height) waits for num_rendered in the middle of the forward to
  * size the binning buffer, like rasterizer_impl.cu:354.  Later calls allocate for a capacity predicted from the previous
- * counts, queue the whole forward, and wait only for the 4-byte count at the very end (an event, not a stream sync); a too
- * small prediction is detected there and the forward is redone with exact sizes.  RADEGS_SPECULATE=0 restores the first
+ * counts, queue the whole forward, and wait only for the 4-byte count at the very end (a mapped host word the emission kernel
+ * writes, polled -- neither an event nor a stream sync); a too small prediction is detected there and the forward is redone with
+ * exact sizes.  RADEGS_SPECULATE=0 restores the first
  * behaviour for every call.  The allocators may therefore be asked for MORE than the exact state size, and -- on a redo --
  * a second time within one call.  The image-state callback is invoked after the capacity is known (its tail holds the
  * sub-tile entry streams of the blend stage when the scene's splats are small). */
@@ -155,8 +158,9 @@ int radegs_backward(const RadegsBwdArgs* args, radegs_alloc_fn accum_alloc, void
  *   before backward.cu:395-403 rescales it), and with require_coord: dL_dview_points[3], dL_dcamera_planes[6], 7 unused
  * holding the values the reference's render kernel leaves in those arrays (rasterizer_impl.cu:541-555).  What summation order does
  * to the gradients is thereby taken out of a comparison: fed with the reference's own sums, every returned gradient must equal the
- * reference's (tests/test_gpu_vs_compiled_reference.py).  Only geom_buffer, the inputs, the camera and the gradient outputs of `args`
- * are read; nothing is allocated. */
+ * reference's (tests/test_gpu_vs_compiled_reference.py).  Of `args`, geom_buffer, radii, means3D, scales + rotations (or cov3D_precomp),
+ * shs (when given), the three camera pointers and the gradient outputs are read -- all must be valid device pointers (NULL is refused);
+ * `sums` must be 16-byte aligned (the records are read as 16-byte pieces).  Nothing is allocated. */
 int radegs_backward_from_sums(const RadegsBwdArgs* args, const float* sums, void* stream);
 
 /* dL_dsh[P,M,3] = scale * sum_v basis(normalize(means3D - campos[v])) (x) drgb_clamped[v]   (rows beyond (D+1)^2 zero).
@@ -223,6 +227,13 @@ long long radegs_debug_export(const char* name, int P, int R, int width, int hei
 /* Speculative binning (see radegs_forward): forwards that ran on a predicted capacity / those whose prediction was too small and
  * were redone with exact sizes, since the last reset. */
 void radegs_binning_stats(unsigned long long* speculative_calls, unsigned long long* misses, int reset);
+/* Which blend formulation the last radegs_forward of the calling thread used: 1 = sub-tile entry streams, 0 = tile-wide kernels,
+ * -1 = no forward yet (bench.py reports the native decision instead of mirroring the selection rule). */
+int radegs_last_forward_used_streams(void);
+
+/* The library reads its environment switches once, at first use.  A host that changes them afterwards --
+ * the test-suite does, between cases of one process -- calls this to have them read again. */
+void radegs_reload_env(void);
 
 /* Per-stage timing with HIP events recorded on the launch stream (used by bench.py for the live
  * roofline measurement).  enable(1) -> every subsequent forward/backward records an event pair per

@@ -139,19 +139,23 @@ template <bool MASKS>
 __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32_t* idx_sorted, const uint32_t* offsets,
                                                             const uint32_t* tiles_touched, const float4* splat_a, const int* radii,
                                                             const uint32_t* rect, int gx, int gy, uint32_t* tile_keys, uint32_t* vals,
-                                                            uint32_t cap, uint32_t* ranges_to_clear, uint32_t* count_mirror, uint32_t* stream_tag, int key16) {
+                                                            uint32_t cap, uint32_t* ranges_to_clear, uint32_t* count_mirror, uint32_t seq, uint32_t* stream_tag, int key16) {
   // key16: tile ids leave as 16-bit keys (grids of at most 65 536 tiles): the tile sort then moves a third less (radegs_sort.hip)
   uint16_t* const tile_keys16 = reinterpret_cast<uint16_t*>(tile_keys);
   // cap: capacity of tile_keys/vals.  With exact allocation it equals num_rendered; in the speculative path (rg_launch.inc)
   // it is a prediction and instances beyond it are dropped here (the host detects the overflow and redoes the binning).
   const int i = blockIdx.x * 256 + threadIdx.x;
   // Two chores that used to be kernels of their own (a 5 us copy and a 5 us fill per forward): the tile ranges start at (0,0)
-  // (rasterizer_impl.cu:383's memset; tile_ranges_kernel runs two sorts later), and num_rendered goes to the host's pinned word
-  // without a copy engine command (the host reads it after the event that follows the whole forward).
+  // (rasterizer_impl.cu:383's memset; tile_ranges_kernel runs two sorts later), and num_rendered goes to the host's pinned words
+  // without a copy engine command or an event: the count, then this forward's sequence number with release order (the host polls the
+  // sequence word once everything else of the forward is queued, rg_launch.inc::binning_finish).
   if (ranges_to_clear) {
     for (int k = i; k < 2 * gx * gy; k += (int)gridDim.x * 256) ranges_to_clear[k] = 0u;
   }
-  if (count_mirror && i == 0) __hip_atomic_store(count_mirror, offsets[P - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (count_mirror && i == 0) {
+    __hip_atomic_store(count_mirror, offsets[P - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(count_mirror + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // PIN_SEQ
+  }
   if (i == 0) *stream_tag = MASKS ? kStreamTag : 0u;   // does this image state hold entry streams?  (ImageState::stream_tag)
   const int lane = threadIdx.x & 63;
   uint32_t idx = 0, ntiles = 0, off = 0;
@@ -377,10 +381,7 @@ __device__ __forceinline__ bool five_sample(const float4 A, const float4 B, floa
 // forward.cu:1003,1121).  Round 1 replayed the test -- five specified exponentials per pair and pass; since round 4 phase 1 leaves one
 // bit per (pixel, entry) in wave-private LDS (64 bits per lane and batch of 64 entries, 12 batches = 6 KB) and phase 2 reads it:
 // the same decisions by construction, no exponential at all in phase 2.  Tiles with more than 768 entries replay as before.
-#if !defined(RADEGS_INTE_BATCHES)
-#define RADEGS_INTE_BATCHES 12   // 16: 5.26 ms on C2 with 4 M points, 12 / 10: 4.87 (LDS per wave decides the occupancy)
-#endif
-constexpr int kUsedBatches = RADEGS_INTE_BATCHES;   // (+ 3 KB of per-pixel staging for the point-major phase 2)
+constexpr int kUsedBatches = 12;   // 16: 5.26 ms on C2 with 4 M points, 12 / 10: 4.87 (LDS per wave decides the occupancy; + 3 KB of per-pixel staging for the point-major phase 2)
 
 __global__ void __launch_bounds__(64) integrate_kernel(const IntegrateArgs a) {
   __shared__ float4 lds_a[64 * 4];
@@ -676,66 +677,19 @@ __device__ __forceinline__ int xcd_band_remap(int b, int n) {
   return xcd * q + (xcd < r ? xcd : r) + loc;
 }
 
-// ---- GROUPED variants (PPL = 2): four 16-lane groups per wave, each walking its OWN culled entry stream -------------------
-// A wave iteration costs the same whether 1 or 64 lanes blend, so what matters is how many iterations a strip needs.  With
-// one stream per wave that is every entry whose {alpha >= 1/255} ellipse touches the 16x8 strip (C2: 256 per strip, 226 of
-// them with a real candidate); a pixel itself needs 65.  Here each DPP row of 16 lanes owns a compact 8x4 block of the strip
-// (2 pixels per lane, rows 2 apart), culls the batch against ITS block (four ballots at staging) and pops its own next entry
-// every iteration: per-lane ctz on a VGPR mask, per-row LDS broadcast reads.  The wave runs max-over-rows iterations
-// (C2: 170 instead of 256).  In the backward the per-Gaussian reduction then IS the row-local part of the butterfly (the four
-// DPP stages, no cross-row exchange) and one 64-lane atomic instruction updates four accumulator lines, one per row.
-// NG = 8 goes one step further: eight 8-lane groups, each owning a 4x4 block (C2: 148 iterations); the reduction is then the
-// three innermost DPP stages and leaves two components per lane (two atomic instructions per iteration).
-struct GroupGeom { int px, py_first, py_step; float rx0, rx1, ry0, ry1; };
-template <int NG> struct GroupShape {   // block of one group inside the 16x8 strip
-  static constexpr int LANES = NG ? 64 / NG : 64, BW = NG == 8 ? 4 : 8, BH = 4, COLS = 16 / BW;
-};
-template <int NG, int PPL>
-__device__ __forceinline__ GroupGeom lane_geometry(int lane, int tile_x, int tile_y, int sub) {
-  GroupGeom g;
-  if constexpr (NG != 0) {
-    using S = GroupShape<NG>;
-    const int grp = lane / S::LANES, l = lane % S::LANES;
-    const int bx = tile_x * 16 + (grp % S::COLS) * S::BW, by = tile_y * 16 + sub * 8 + (grp / S::COLS) * S::BH;
-    g.px = bx + (l % S::BW); g.py_first = by + (l / S::BW); g.py_step = 2;
-    g.rx0 = (float)bx; g.rx1 = g.rx0 + (float)(S::BW - 1); g.ry0 = (float)by; g.ry1 = g.ry0 + (float)(S::BH - 1);
-  } else {
-    g.px = tile_x * 16 + (lane & 15); g.py_first = tile_y * 16 + sub * (4 * PPL) + (lane >> 4); g.py_step = 4;
-    g.rx0 = (float)(tile_x * 16); g.rx1 = g.rx0 + 15.0f; g.ry0 = (float)(tile_y * 16 + sub * (4 * PPL)); g.ry1 = g.ry0 + (float)(4 * PPL - 1);
-  }
+// One wave64 owns a 16 x (4*PPL) strip of the tile: lane -> column (lane & 15), rows (lane >> 4) + 4 s.
+struct StripGeom { int px, py_first; float rx0, rx1, ry0, ry1; };
+template <int PPL>
+__device__ __forceinline__ StripGeom lane_geometry(int lane, int tile_x, int tile_y, int sub) {
+  StripGeom g;
+  g.px = tile_x * 16 + (lane & 15); g.py_first = tile_y * 16 + sub * (4 * PPL) + (lane >> 4);
+  g.rx0 = (float)(tile_x * 16); g.rx1 = g.rx0 + 15.0f; g.ry0 = (float)(tile_y * 16 + sub * (4 * PPL)); g.ry1 = g.ry0 + (float)(4 * PPL - 1);
   return g;
 }
-// The batch's survivor mask of this lane's group: lane k holds entry k's record and tests it against every group's block (the
-// ellipse extents of entry_may_touch are computed once, the per-block part is four compares).  niter (wave-uniform, scalar):
-// the longest of the streams = the number of iterations the wave runs for this batch.
-template <int NG>
-__device__ __forceinline__ uint64_t group_masks(bool valid, const float4 q0, const float4 q1, int tile_x, int tile_y, int sub, int lane,
-                                                int& niter) {
-  using S = GroupShape<NG>;
-  const float mx = q0.x, my = q0.y, cx = q0.z, cy = q0.w, cz = q1.x, thr = q1.z;
-  const float det = cx * cz - cy * cy;
-  const float r = (-2.0f * thr) / det;
-  const float hx = sqrtf(r * cz) * 1.001f + 0.01f, hy = sqrtf(r * cx) * 1.001f + 0.01f;
-  const float xl = mx - hx, xh = mx + hx, yl = my - hy, yh = my + hy;
-  const bool never = thr > 0.0f;
-  const bool definite = (det > 0.0f) && (cx > 0.0f) && (cz > 0.0f);   // otherwise the extents are meaningless: keep (see entry_may_touch)
-  uint64_t mine = 0;
-  niter = 0;
-#pragma unroll
-  for (int grp = 0; grp < NG; grp++) {
-    const float bx = (float)(tile_x * 16 + (grp % S::COLS) * S::BW), by = (float)(tile_y * 16 + sub * 8 + (grp / S::COLS) * S::BH);
-    const bool off = ((xh < bx) || (xl > bx + (float)(S::BW - 1)) || (yh < by) || (yl > by + (float)(S::BH - 1))) && definite;  // NaN: keep
-    const uint64_t m = __ballot(valid && !off && !never);
-    niter = max(niter, (int)__popcll(m));
-    if (lane / S::LANES == grp) mine = m;
-  }
-  return mine;
-}
+constexpr int kStripRowStep = 4;   // rows between the pixels of one lane
 
-template <bool COORD, bool DEPTH, int PPL, int NG = 0>
+template <bool COORD, bool DEPTH, int PPL>
 __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
-  constexpr bool GROUPED = NG != 0;
-  static_assert(!GROUPED || PPL == 2, "grouped streams are built for 2 pixels per lane");
   constexpr bool NORMAL = COORD || DEPTH;
   constexpr int WPT = 4 / PPL;  // waves per tile
   __shared__ float4 lds_a[65 * 4];
@@ -745,13 +699,13 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
   const int tile = item / WPT, sub = item - tile * WPT;
   const int tile_x = tile % a.gx, tile_y = tile / a.gx;
   const int lane = threadIdx.x;
-  const GroupGeom geo = lane_geometry<NG, PPL>(lane, tile_x, tile_y, sub);
+  const StripGeom geo = lane_geometry<PPL>(lane, tile_x, tile_y, sub);
   const int px = geo.px;
-  const int py0 = geo.py_first;  // slot s -> row py0 + py_step*s
+  const int py0 = geo.py_first;  // slot s -> row py0 + 4 s
   const int W = a.W, H = a.H;
   const size_t HW = (size_t)H * W;
   const float pixfx = (float)px;
-  // pixel rectangle owned by this wave (for batch culling; per group in the GROUPED variant)
+  // pixel rectangle owned by this wave (for batch culling)
   const float reg_x0 = geo.rx0, reg_x1 = geo.rx1, reg_y0 = geo.ry0, reg_y1 = geo.ry1;
 
   const uint2 range = a.ranges[tile];
@@ -766,7 +720,7 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
   bool inside[PPL];
 #pragma unroll
   for (int s = 0; s < PPL; s++) {
-    const int py = py0 + geo.py_step * s;
+    const int py = py0 + kStripRowStep * s;
     pixfy[s] = (float)py;
     inside[s] = px < W && py < H;
     T[s] = 1.0f; Tw[s] = inside[s] ? 1.0f : 0.0f; Cr[s] = Cg[s] = Cb[s] = 0.f; weight[s] = 0.f;
@@ -790,7 +744,6 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
     __syncthreads();
     const int k = base + lane;
     bool rel_lane = false;
-    float4 gq0 = make_float4(0.f, 0.f, 0.f, 0.f), gq1 = gq0;
     if (k < n) {
       const uint32_t g = a.point_list[range.x + k];
       const float4* src = a.splat_a + 4 * (size_t)g;
@@ -800,18 +753,14 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
         const float4* sb = a.splat_b + 3 * (size_t)g;
         lds_b[lane * 3 + 0] = sb[0]; lds_b[lane * 3 + 1] = sb[1]; lds_b[lane * 3 + 2] = sb[2];
       }
-      if constexpr (!GROUPED) rel_lane = entry_may_touch(q0, q1, reg_x0, reg_x1, reg_y0, reg_y1);
-      if constexpr (GROUPED) { gq0 = q0; gq1 = q1; }
+      rel_lane = entry_may_touch(q0, q1, reg_x0, reg_x1, reg_y0, reg_y1);
     }
-    uint64_t rel;
-    int niter = 0;
-    if constexpr (GROUPED) rel = group_masks<NG>(k < n, gq0, gq1, tile_x, tile_y, sub, lane, niter);  // per-lane (per-group) value
-    else { rel = __ballot(rel_lane); niter = (int)__popcll(rel); }
+    uint64_t rel = __ballot(rel_lane);
+    const int niter = (int)__popcll(rel);
     __syncthreads();
-    for (int it = 0; it < niter && !all_done; it++) {   // scalar trip count in both variants
-      const bool idle = GROUPED && rel == 0;   // this row's stream is exhausted for the batch
-      const int j = idle ? 0 : __builtin_ctzll(rel);
-      rel &= rel - 1;                           // 0 stays 0
+    for (int it = 0; it < niter && !all_done; it++) {   // scalar trip count
+      const int j = __builtin_ctzll(rel);
+      rel &= rel - 1;
       const float4 A = lds_a[j * 4 + 0], B = lds_a[j * 4 + 1];  // {mx,my,cx,cy} {cz,op,thr,ts}
       const float dx = A.x - pixfx;
       const float a_x = (A.z * dx) * dx;
@@ -822,7 +771,7 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
       for (int s = 0; s < PPL; s++) {
         const float dy = A.y - pixfy[s];
         power[s] = splat_power(a_x, b_xy, B.x, dy);
-        cand[s] = !idle && !(power[s] > 0.0f) && !(power[s] < B.z);
+        cand[s] = !(power[s] > 0.0f) && !(power[s] < B.z);
         anyc = anyc || cand[s];
       }
       if (__any(anyc)) {  // (no `continue`: a single loop back-edge keeps the per-pixel state in place, no PHI copies)
@@ -885,7 +834,7 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
 #pragma unroll
   for (int s = 0; s < PPL; s++) {
     if (!inside[s]) continue;
-    const size_t pix = (size_t)W * (py0 + geo.py_step * s) + px;
+    const size_t pix = (size_t)W * (py0 + kStripRowStep * s) + px;
     const float pny = (pixfy[s] - H / 2.f) / a.focal_y;
     const float ln = sqrtf(pnx * pnx + pny * pny + 1);
     a.n_contrib[pix] = last_c[s];
@@ -943,6 +892,7 @@ struct BlendBwdArgs {
   const float* dL_dalpha; const float* dL_dnormal;
   float* acc;  // [P][REC] per-Gaussian sums, SplatAcc order
   const uint32_t* stream_tag;   // ImageState::stream_tag (stream kernels only)
+  uint32_t* stream_err;         // mapped host word: set when stream_tag says this buffer holds no entry streams (may be nullptr)
   const uint32_t* blk_consumed; const uint32_t* blk_chunks; const uint32_t* blk_order;   // sub-tile entry streams (rg_streams.inc)
 };
 
@@ -967,7 +917,7 @@ __device__ __forceinline__ void bfly_stage_dpp(float* v, int lane) {
   }
 }
 template <int HALF, int BIT>
-__device__ __forceinline__ void bfly_stage_xor(float* v, int lane) {
+__device__ __forceinline__ void bfly_stage_xor(float* v, int lane) {   // a stage that crosses the DPP rows (ds_bpermute)
   const bool up = (lane >> BIT) & 1;
 #pragma unroll
   for (int i = 0; i < HALF; i++) {
@@ -976,283 +926,17 @@ __device__ __forceinline__ void bfly_stage_xor(float* v, int lane) {
     v[i] = keep + __shfl_xor(send, 1 << BIT);
   }
 }
-template <int N, bool DPP>
+template <int N>
 __device__ __forceinline__ float wave_reduce_scatter(float (&v)[N], int lane) {
   if constexpr (N == 32) bfly_stage_xor<16, 4>(v, lane);
-  if constexpr (DPP) {
-    bfly_stage_dpp<8, 3, 0x128>(v, lane);  // row_ror:8
-    bfly_stage_dpp<4, 2, 0x141>(v, lane);  // row_half_mirror
-    bfly_stage_dpp<2, 1, 0x4E>(v, lane);   // quad_perm [2,3,0,1]
-    bfly_stage_dpp<1, 0, 0xB1>(v, lane);   // quad_perm [1,0,3,2]
-  } else {
-    bfly_stage_xor<8, 3>(v, lane);
-    bfly_stage_xor<4, 2>(v, lane);
-    bfly_stage_xor<2, 1>(v, lane);
-    bfly_stage_xor<1, 0>(v, lane);
-  }
+  bfly_stage_dpp<8, 3, 0x128>(v, lane);  // row_ror:8
+  bfly_stage_dpp<4, 2, 0x141>(v, lane);  // row_half_mirror
+  bfly_stage_dpp<2, 1, 0x4E>(v, lane);   // quad_perm [2,3,0,1]
+  bfly_stage_dpp<1, 0, 0xB1>(v, lane);   // quad_perm [1,0,3,2]
   float r = v[0];
   if constexpr (N == 16) r += __shfl_xor(r, 16);
   r += __shfl_xor(r, 32);
   return r;
-}
-
-// second launch-bound = waves per SIMD the register allocator must leave room for
-template <bool COORD, bool DEPTH, int PPL, bool DPP>
-__global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 2 : (PPL == 2 ? 3 : 5)) : (PPL == 4 ? 3 : (PPL == 2 ? 4 : 6)))) blend_bwd_kernel(const BlendBwdArgs a) {
-  constexpr bool NORMAL = COORD || DEPTH;
-  constexpr int WPT = 4 / PPL;
-  constexpr int REC = COORD ? 32 : 16;
-  __shared__ float4 lds_a[65 * 4];
-  __shared__ float4 lds_b[COORD ? 64 * 3 : 1];
-  __shared__ uint32_t lds_id[64];
-
-  const int item = xcd_band_remap(blockIdx.x, gridDim.x);
-  const int tile = item / WPT, sub = item - tile * WPT;
-  const int tile_x = tile % a.gx, tile_y = tile / a.gx;
-  const int lane = threadIdx.x, lx = lane & 15, lr = lane >> 4;
-  const int px = tile_x * 16 + lx;
-  const int py0 = tile_y * 16 + sub * (4 * PPL) + lr;
-  const int W = a.W, H = a.H;
-  const size_t HW = (size_t)H * W;
-  const float pixfx = (float)px;
-  const uint2 range = a.ranges[tile];
-
-  // ---- per-pixel prologue (backward.cu:706-781) ----
-  // The reference keeps last_alpha/last_color/... and folds the PREVIOUS contributor into the
-  // "behind" accumulators at the start of the next one (backward.cu:870,900,930,949,962).  Folding
-  // the CURRENT contributor in at the end of its own iteration is the same arithmetic on the same
-  // operands (bit-identical values), and needs no last_* registers or copies.
-  float pixfy[PPL], T[PPL], acc_a[PPL], dLa[PPL], tb[PPL];
-  float dLc[PPL][3], accC[PPL][3];
-  float dLt[PPL], dLmt[PPL], accT[PPL];
-  float dLn[PPL][3], accN[PPL][3];
-  float dLco[COORD ? PPL : 1][3], dLmco[COORD ? PPL : 1][3], accCo[COORD ? PPL : 1][3];
-  uint32_t last_c[PPL], max_cm1[PPL];
-  uint32_t wave_last = 0;
-  const float pnx = (pixfx - W / 2.f) / a.focal_x;
-#pragma unroll
-  for (int s = 0; s < PPL; s++) {
-    const int py = py0 + 4 * s;
-    pixfy[s] = (float)py;
-    const bool inside = px < W && py < H;
-    const size_t pix = inside ? (size_t)W * py + px : 0;
-    const float alpha_px = inside ? a.alphas[pix] : 0.f;
-    const float T_final = inside ? (1 - alpha_px) : 0.f;
-    const float w_final = alpha_px;
-    T[s] = T_final;
-    last_c[s] = inside ? a.n_contrib[pix] : 0u;
-    max_cm1[s] = (inside ? a.n_contrib[pix + HW] : 0u) - 1u;  // compared against the 0-based position
-    wave_last = max(wave_last, last_c[s]);
-    acc_a[s] = 0.f;
-    dLt[s] = dLmt[s] = 0.f; accT[s] = 0.f;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      dLc[s][c] = inside ? a.dL_dpix[c * HW + pix] : 0.f;
-      accC[s][c] = 0.f;
-      dLn[s][c] = 0.f; accN[s][c] = 0.f;
-      if constexpr (COORD) { dLco[s][c] = dLmco[s][c] = 0.f; accCo[s][c] = 0.f; }
-    }
-    dLa[s] = inside ? a.dL_dalpha[pix] : 0.f;
-    // background term of dL/dalpha: (-T_final/(1-alpha)) * <bg, dL_dpixel>  (backward.cu:972-975)
-    tb[s] = -T_final * (a.bg[0] * dLc[s][0] + a.bg[1] * dLc[s][1] + a.bg[2] * dLc[s][2]);
-    // Pixels nothing blended into (alpha = 0) cannot pass a gradient to any Gaussian; their 1/alpha factors would be inf/NaN and
-    // poison the wave-wide sums through the multiplicative masks, so their geometry cotangents stay zero.
-    if (NORMAL && inside && last_c[s] > 0) {
-      const float ww = w_final * w_final;
-      const float pny = (pixfy[s] - H / 2.f) / a.focal_y;
-      const float ln = sqrtf(pnx * pnx + pny * pny + 1);
-      if constexpr (COORD) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-          const float gw = a.dL_dcoord[c * HW + pix];
-          dLa[s] -= gw * a.accum_coord[c * HW + pix] / ww;
-          dLco[s][c] = gw / w_final;
-          dLmco[s][c] = a.dL_dmcoord[c * HW + pix];
-        }
-      }
-      if constexpr (DEPTH) {
-        const float gw = a.dL_ddepth[pix];
-        dLa[s] -= gw * a.accum_depth[pix] / ww;
-        dLt[s] = gw / w_final / ln;
-        dLmt[s] = a.dL_dmdepth[pix] / ln;
-      }
-      {
-        const float g0 = a.dL_dnormal[pix], g1 = a.dL_dnormal[HW + pix], g2 = a.dL_dnormal[2 * HW + pix];
-        const float n0 = a.normalmap[pix], n1 = a.normalmap[HW + pix], n2 = a.normalmap[2 * HW + pix];
-        const float nlen = a.normal_length[pix];
-        if (nlen < 1.0E-12F) {
-          dLn[s][0] = g0 / 1.0E-12F; dLn[s][1] = g1 / 1.0E-12F; dLn[s][2] = g2 / 1.0E-12F;
-        } else {
-          const float dt = g0 * n0 + g1 * n1 + g2 * n2;
-          dLn[s][0] = (g0 - dt * n0) / nlen; dLn[s][1] = (g1 - dt * n1) / nlen; dLn[s][2] = (g2 - dt * n2) / nlen;
-        }
-      }
-    }
-  }
-  // entries at or beyond the furthest last contributor of this strip contribute to no pixel
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, m));
-  const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-
-  for (int hi = (int)wave_last; hi > 0; hi -= 64) {
-    __syncthreads();
-    const int e = hi - 1 - lane;
-    if (e >= 0) {
-      const uint32_t g = a.point_list[range.x + e];
-      lds_id[lane] = g;
-      const float4* src = a.splat_a + 4 * (size_t)g;
-      const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
-      lds_a[lane * 4 + 0] = q0; lds_a[lane * 4 + 1] = q1; lds_a[lane * 4 + 2] = q2; lds_a[lane * 4 + 3] = q3;
-      if constexpr (COORD) {
-        const float4* sb = a.splat_b + 3 * (size_t)g;
-        lds_b[lane * 3 + 0] = sb[0]; lds_b[lane * 3 + 1] = sb[1]; lds_b[lane * 3 + 2] = sb[2];
-      }
-    }
-    __syncthreads();
-    const int cnt = min(64, hi);
-    float4 nA = lds_a[0], nB = lds_a[1];
-    for (int j = 0; j < cnt; j++) {
-      const float4 A = nA, B = nB;
-      nA = lds_a[(j + 1) * 4 + 0];
-      nB = lds_a[(j + 1) * 4 + 1];
-      const uint32_t pos = (uint32_t)(hi - 1 - j);  // 0-based list position == `contributor`
-      const float dx = A.x - pixfx;
-      const float a_x = (A.z * dx) * dx;
-      const float b_xy = A.w * dx;
-      float power[PPL];
-      bool cand[PPL], anyc = false;
-#pragma unroll
-      for (int s = 0; s < PPL; s++) {
-        const float dy = A.y - pixfy[s];
-        power[s] = splat_power(a_x, b_xy, B.x, dy);
-        cand[s] = (pos < last_c[s]) && !(power[s] > 0.0f) && !(power[s] < B.z);
-        anyc = anyc || cand[s];
-      }
-      if (!__any(anyc)) continue;
-      const float4 C = lds_a[j * 4 + 2], Dq = lds_a[j * 4 + 3];
-      float4 E0, E1, E2;
-      if constexpr (COORD) { E0 = lds_b[j * 3 + 0]; E1 = lds_b[j * 3 + 1]; E2 = lds_b[j * 3 + 2]; }
-      float gv[REC];
-#pragma unroll
-      for (int i = 0; i < REC; i++) gv[i] = 0.f;
-      bool contributed = false;
-      const float dxx = dx * dx;
-#pragma unroll
-      for (int s = 0; s < PPL; s++) {
-        if (cand[s]) {
-          // alpha.  The DECISION alpha < 1/255 must be the forward's (exp_spec); the VALUE may come from
-          // the hardware exp (3e-7 relative): only when op*exp is within 1e-4 of the threshold is the
-          // specified exponential evaluated, so the decision is always the exact one.
-#if defined(RADEGS_BWD_EXACT)   // analysis build (scripts/gpu_fuzz_table.py): the oracle's arithmetic for alpha and T
-          float G = exp_spec(power[s]);
-          float a_raw = B.y * G;
-#else
-          float G = __expf(power[s]);
-          float a_raw = B.y * G;
-          if (fabsf(fmaf(a_raw, 255.0f, -1.0f)) < 1.0e-4f) {
-            G = exp_spec(power[s]);
-            a_raw = B.y * G;
-          }
-#endif
-          const float alpha = fminf(0.99f, a_raw);
-          if (!(alpha < 1.0f / 255.0f)) {
-            contributed = true;
-            const float dy = A.y - pixfy[s];
-            const float one_m_a = 1.f - alpha;
-#if defined(RADEGS_BWD_EXACT)
-            const float inv1ma = 1.0f / one_m_a;
-#else
-            const float inv1ma = rcp_refined(one_m_a);  // no decision depends on T here; the refinement keeps the T chain at division accuracy
-#endif
-            T[s] = T[s] * inv1ma;
-            const float dch = alpha * T[s];
-            float dL_dopa = 0.f;
-            // "behind" accumulators: acc <- alpha*v + (1-alpha)*acc == acc + alpha*(v - acc)
-            {
-              const float col[3] = {C.x, C.y, C.z};
-#pragma unroll
-              for (int c = 0; c < 3; c++) {
-                const float dd = col[c] - accC[s][c];
-                dL_dopa = fmaf(dd, dLc[s][c], dL_dopa);
-                gv[c] = fmaf(dch, dLc[s][c], gv[c]);
-                accC[s][c] = fmaf(alpha, dd, accC[s][c]);
-              }
-            }
-            float dco[3] = {0.f, 0.f, 0.f}, dt_ = 0.f;
-            const bool is_median = pos == max_cm1[s];
-            if constexpr (COORD) {
-              const float cpx[3] = {E0.x, E0.z, E1.x}, cpy[3] = {E0.y, E0.w, E1.y}, vp[3] = {E1.z, E1.w, E2.x};
-#pragma unroll
-              for (int c = 0; c < 3; c++) {
-                const float cc = fmaf(cpy[c], dy, fmaf(cpx[c], dx, vp[c]));
-                const float dd = cc - accCo[s][c];
-                dL_dopa = fmaf(dd, dLco[s][c], dL_dopa);
-                accCo[s][c] = fmaf(alpha, dd, accCo[s][c]);
-                dco[c] = dch * dLco[s][c];
-                if (is_median) dco[c] += dLmco[s][c];
-                gv[16 + c] += dco[c];
-                gv[19 + 2 * c] = fmaf(dco[c], dx, gv[19 + 2 * c]);  // 1/focal applied per Gaussian later
-                gv[20 + 2 * c] = fmaf(dco[c], dy, gv[20 + 2 * c]);
-              }
-            }
-            if constexpr (DEPTH) {
-              const float t = B.w + fmaf(C.w, dx, Dq.x * dy);
-              const float dd = t - accT[s];
-              dL_dopa = fmaf(dd, dLt[s], dL_dopa);
-              accT[s] = fmaf(alpha, dd, accT[s]);
-              dt_ = dch * dLt[s];
-              if (is_median) dt_ += dLmt[s];
-              gv[3] += dt_;
-              gv[4] = fmaf(dt_, dx, gv[4]);  // 1/focal applied per Gaussian later
-              gv[5] = fmaf(dt_, dy, gv[5]);
-            }
-            if constexpr (NORMAL) {
-              const float nn[3] = {Dq.y, Dq.z, Dq.w};
-#pragma unroll
-              for (int c = 0; c < 3; c++) {
-                const float dd = nn[c] - accN[s][c];
-                dL_dopa = fmaf(dd, dLn[s][c], dL_dopa);
-                gv[6 + c] = fmaf(dch, dLn[s][c], gv[6 + c]);
-                accN[s][c] = fmaf(alpha, dd, accN[s][c]);
-              }
-            }
-            const float da = 1.f - acc_a[s];
-            dL_dopa = fmaf(da, dLa[s], dL_dopa);
-            acc_a[s] = fmaf(alpha, da, acc_a[s]);
-            dL_dopa *= T[s];
-            dL_dopa = fmaf(inv1ma, tb[s], dL_dopa);
-
-            // d/d(mean2D, conic, opacity) through G = exp(power):  u = G*dL_dopa,  h = op*u = G*dL_dG
-            const float u = G * dL_dopa;
-            const float h = B.y * u;
-            const float ex = fmaf(dy, A.w, dx * A.z);   // dx*cx + dy*cy
-            const float ey = fmaf(dx, A.w, dy * B.x);   // dy*cz + dx*cy
-            const float gx_ = -h * ex, gy_ = -h * ey;   // dL_dG * dG_ddelx, dL_dG * dG_ddely
-            float dL_ddelx = gx_, dL_ddely = gy_;
-            if constexpr (COORD) {
-              dL_ddelx += dco[0] * E0.x + dco[1] * E0.z + dco[2] * E1.x;
-              dL_ddely += dco[0] * E0.y + dco[1] * E0.w + dco[2] * E1.y;
-            }
-            if constexpr (DEPTH) {
-              dL_ddelx = fmaf(dt_, C.w, dL_ddelx);
-              dL_ddely = fmaf(dt_, Dq.x, dL_ddely);
-            }
-            gv[9] += dL_ddelx;    // x W/2, y H/2 applied per Gaussian later
-            gv[10] += dL_ddely;
-            gv[11] = fmaf(fabsf(gy_), ddely_dy, fmaf(fabsf(gx_), ddelx_dx, gv[11]));
-            const float hh = -0.5f * h;
-            gv[12] = fmaf(hh, dxx, gv[12]);
-            gv[13] = fmaf(hh, dx * dy, gv[13]);
-            gv[14] = fmaf(hh, dy * dy, gv[14]);
-            gv[15] += u;
-          }
-        }
-      }
-      if (!__any(contributed)) continue;
-      const float tot = wave_reduce_scatter<REC, DPP>(gv, lane);
-      if (lane < (COORD ? 25 : 16)) unsafeAtomicAdd(a.acc + (size_t)lds_id[j] * REC + lane, tot);
-    }
-  }
 }
 
 // ------------------------------------------------------------------ blend, bwd (packed) ----
@@ -1266,33 +950,10 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 bc2(float v) { return f2{v, v}; }
 
-// the row-local part of the butterfly: N components over the 16 lanes of a DPP row.  N = 16: lane l ends with the row total of
-// component l in v[0]; N = 32: with components 2l and 2l+1 in v[0], v[1].
-// LANES = 16 (N components -> N/16 per lane: lane l holds components l*N/16 ...) or 8 (half rows: N/8 per lane, l = lane & 7).
-template <int N, int LANES>
-__device__ __forceinline__ void row_reduce_scatter(float (&v)[N], int lane) {
-  if constexpr (LANES == 16) {
-    bfly_stage_dpp<N / 2, 3, 0x128>(v, lane);   // row_ror:8
-    bfly_stage_dpp<N / 4, 2, 0x141>(v, lane);   // row_half_mirror
-    bfly_stage_dpp<N / 8, 1, 0x4E>(v, lane);    // quad_perm [2,3,0,1]
-    bfly_stage_dpp<N / 16, 0, 0xB1>(v, lane);   // quad_perm [1,0,3,2]
-  } else {
-    bfly_stage_dpp<N / 2, 2, 0x141>(v, lane);   // row_half_mirror
-    bfly_stage_dpp<N / 4, 1, 0x4E>(v, lane);    // quad_perm [2,3,0,1]
-    bfly_stage_dpp<N / 8, 0, 0xB1>(v, lane);    // quad_perm [1,0,3,2]
-  }
-}
-
-// LINEWISE (coord map, four streams; RADEGS_BWD_LINEWISE=1 -- written at the end of round 4, not yet run on a GPU, off by default): the
-// generic 32-component reduce-scatter leaves lane l with components 2l, 2l + 1, so both atomic instructions of a (row, entry) write into
-// BOTH 64-byte lines of the record -- four line updates instead of two, which is what "with the coord map's 32-float records even four
-// streams saturate the atomic units" (rg_launch.inc: auto_streams) was measured on.  Two 16-component reductions give lane l the
-// components l and 16 + l: one line per instruction.
-template <bool COORD, bool DEPTH, int PPL, int NG = 0, bool LINEWISE = false>
-__global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 2 : (NG ? 4 : 5)))) blend_bwd_packed_kernel(const BlendBwdArgs a) {
-  constexpr bool GROUPED = NG != 0;
+// second launch-bound = waves per SIMD the register allocator must leave room for
+template <bool COORD, bool DEPTH, int PPL>
+__global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 2 : 5))) blend_bwd_packed_kernel(const BlendBwdArgs a) {
   static_assert(PPL == 2 || PPL == 4, "pairs of pixels per lane");
-  static_assert(!GROUPED || PPL == 2, "grouped streams are built for 2 pixels per lane");
   constexpr bool NORMAL = COORD || DEPTH;
   constexpr int NP = PPL / 2;  // pairs per lane
   constexpr int WPT = 4 / PPL;
@@ -1305,7 +966,7 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
   const int tile = item / WPT, sub = item - tile * WPT;
   const int tile_x = tile % a.gx, tile_y = tile / a.gx;
   const int lane = threadIdx.x;
-  const GroupGeom geo = lane_geometry<NG, PPL>(lane, tile_x, tile_y, sub);
+  const StripGeom geo = lane_geometry<PPL>(lane, tile_x, tile_y, sub);
   const int px = geo.px;
   const int py0 = geo.py_first;
   const int W = a.W, H = a.H;
@@ -1331,7 +992,7 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
 #pragma unroll
   for (int s = 0; s < PPL; s++) {
     const int q = s >> 1, e = s & 1;
-    const int py = py0 + geo.py_step * s;
+    const int py = py0 + kStripRowStep * s;
     pixfy[q][e] = (float)py;
     const bool inside = px < W && py < H;
     const size_t pix = inside ? (size_t)W * py + px : 0;
@@ -1397,7 +1058,6 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
     __syncthreads();
     const int e0 = hi - 1 - lane;
     bool rel_lane = false;
-    float4 gq0 = make_float4(0.f, 0.f, 0.f, 0.f), gq1 = gq0;
     if (e0 >= 0) {
       const uint32_t g = a.point_list[range.x + e0];
       lds_id[lane] = g;
@@ -1408,18 +1068,14 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
         const float4* sb = a.splat_b + 3 * (size_t)g;
         lds_b[lane * 3 + 0] = sb[0]; lds_b[lane * 3 + 1] = sb[1]; lds_b[lane * 3 + 2] = sb[2];
       }
-      if constexpr (GROUPED) { gq0 = q0; gq1 = q1; }
-      else rel_lane = entry_may_touch(q0, q1, reg_x0, reg_x1, reg_y0, reg_y1);
+      rel_lane = entry_may_touch(q0, q1, reg_x0, reg_x1, reg_y0, reg_y1);
     }
-    uint64_t rel;
-    int niter = 0;
-    if constexpr (GROUPED) rel = group_masks<NG>(e0 >= 0, gq0, gq1, tile_x, tile_y, sub, lane, niter);  // per-group value
-    else { rel = __ballot(rel_lane); niter = (int)__popcll(rel); }
+    uint64_t rel = __ballot(rel_lane);
+    const int niter = (int)__popcll(rel);
     __syncthreads();
-    for (int it = 0; it < niter; it++) {   // scalar trip count in both variants
-      const bool idle = GROUPED && rel == 0;   // this row's stream is exhausted for the batch
-      const int j = idle ? 0 : __builtin_ctzll(rel);  // LDS slot j holds list position hi-1-j: ascending j = back to front
-      rel &= rel - 1;                                  // 0 stays 0
+    for (int it = 0; it < niter; it++) {   // scalar trip count
+      const int j = __builtin_ctzll(rel);  // LDS slot j holds list position hi-1-j: ascending j = back to front
+      rel &= rel - 1;
       const float4 A = lds_a[j * 4 + 0], B = lds_a[j * 4 + 1], C = lds_a[j * 4 + 2], Dq = lds_a[j * 4 + 3];
       const uint32_t gid = lds_id[j];
       const uint32_t pos = (uint32_t)(hi - 1 - j);
@@ -1437,7 +1093,7 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
 #pragma unroll
         for (int e = 0; e < 2; e++) {
           const float pw = power[q][e];
-          cand[2 * q + e] = !idle && (pos < last_c[2 * q + e]) && !(pw > 0.0f) && !(pw < B.z);
+          cand[2 * q + e] = (pos < last_c[2 * q + e]) && !(pw > 0.0f) && !(pw < B.z);
           anyc = anyc || cand[2 * q + e];
         }
       }
@@ -1453,11 +1109,7 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
       for (int q = 0; q < NP; q++) {
         if (!__any(cand[2 * q] || cand[2 * q + 1])) continue;  // wave-uniform
         // ---- alpha (decision = forward's exp_spec rule; value from the hardware exp) ----
-#if defined(RADEGS_BWD_EXACT)   // analysis build (scripts/gpu_fuzz_table.py): the oracle's arithmetic for alpha and T
-        f2 G = f2{exp_spec(power[q][0]), exp_spec(power[q][1])};
-#else
         f2 G = f2{__expf(power[q][0]), __expf(power[q][1])};
-#endif
         f2 a_raw = bc2(B.y) * G;
         {
           const bool b0 = fabsf(fmaf(a_raw[0], 255.0f, -1.0f)) < 1.0e-4f, b1 = fabsf(fmaf(a_raw[1], 255.0f, -1.0f)) < 1.0e-4f;
@@ -1472,11 +1124,7 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
         alpha = f2{act0 ? alpha[0] : 0.f, act1 ? alpha[1] : 0.f};
         G = f2{act0 ? G[0] : 0.f, act1 ? G[1] : 0.f};
         const f2 one_m_a = bc2(1.f) - alpha;
-#if defined(RADEGS_BWD_EXACT)
-        const f2 inv1ma = f2{1.0f / one_m_a[0], 1.0f / one_m_a[1]};
-#else
         const f2 inv1ma = f2{rcp_refined(one_m_a[0]), rcp_refined(one_m_a[1])};
-#endif
         T[q] = T[q] * inv1ma;
         const f2 dch = alpha * T[q];
         // V = <cotangent of this pixel, blended quantities of this Gaussian>; dL/dalpha's blend part = V - Q
@@ -1554,40 +1202,8 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
       float gs[REC];
 #pragma unroll
       for (int i = 0; i < REC; i++) gs[i] = gv[i][0] + gv[i][1];
-      if constexpr (GROUPED) {
-        // every row reduces ITS entry's 16 (32) components over its 16 lanes; rows nobody contributed in skip the update
-        constexpr int GL = GroupShape<NG>::LANES, PER = REC / GL;   // components left per lane: comps l*PER .. l*PER+PER-1
-        const bool grp_live = ((contrib_mask >> (lane & ~(GL - 1))) & ((1ull << GL) - 1ull)) != 0;
-        const int l = lane & (GL - 1);
-        if constexpr (COORD && LINEWISE && GL == 16) {
-          row_reduce_scatter<16, 16>(*reinterpret_cast<float (*)[16]>(gs), lane);        // lane l: component l
-          row_reduce_scatter<16, 16>(*reinterpret_cast<float (*)[16]>(gs + 16), lane);   // lane l: component 16 + l
-          if (grp_live) {
-            unsafeAtomicAdd(a.acc + (size_t)gid * REC + l, gs[0]);
-            if (l < 9) unsafeAtomicAdd(a.acc + (size_t)gid * REC + 16 + l, gs[16]);
-          }
-        } else {
-          row_reduce_scatter<REC, GL>(gs, lane);
-          if (grp_live) {
-#pragma unroll
-            for (int i = 0; i < PER; i++)
-              if (l * PER + i < (COORD ? 25 : 16)) unsafeAtomicAdd(a.acc + (size_t)gid * REC + l * PER + i, gs[i]);
-          }
-        }
-      } else if constexpr (COORD && LINEWISE) {
-        // (prepared with the variant above, not yet run on a GPU)  The 32-component wave reduction opens with a cross-row stage: 16
-        // ds_bpermute + 32 selects per entry (23 bpermutes in all).  Two 16-component reductions stay inside the DPP rows for four
-        // stages each and cross the rows only with their single result: 30 DPP adds + 4 bpermutes.  Rows 0 and 1 then carry the two lines.
-        const float lo = wave_reduce_scatter<16, true>(*reinterpret_cast<float (*)[16]>(gs), lane);
-        const float hi = wave_reduce_scatter<16, true>(*reinterpret_cast<float (*)[16]>(gs + 16), lane);
-        if (lane < 25) unsafeAtomicAdd(a.acc + (size_t)gid * REC + lane, lane < 16 ? lo : hi);
-      } else {
-        const float tot = wave_reduce_scatter<REC, true>(gs, lane);
-#if defined(RADEGS_EXP_NOATOMIC)      // timing experiment (scripts/build_alt.py): everything but the atomic (a.W < 0 never holds)
-        if (a.W < 0)
-#endif
-        if (lane < (COORD ? 25 : 16)) unsafeAtomicAdd(a.acc + (size_t)gid * REC + lane, tot);
-      }
+      const float tot = wave_reduce_scatter<REC>(gs, lane);
+      if (lane < (COORD ? 25 : 16)) unsafeAtomicAdd(a.acc + (size_t)gid * REC + lane, tot);
     }
   }
 }
@@ -1627,10 +1243,7 @@ __global__ void __launch_bounds__(256) drgb_clamped_kernel(int P, const int* __r
 // written by one thread each they would be 64 different cache lines per instruction.  The block therefore
 // moves its contiguous 128-row slab with coalesced accesses through LDS (row stride 3M+1 words: odd, so the
 // per-thread row walks are bank-conflict free); sh and dL/dsh share the slab (sh_bwd's access order allows it).
-#ifndef RADEGS_PREBWD_THREADS
-#define RADEGS_PREBWD_THREADS 128   // measured, round 4 (scripts/build_alt.py): see DESIGN.md 4.5
-#endif
-constexpr int kPreBwdThreads = RADEGS_PREBWD_THREADS;
+constexpr int kPreBwdThreads = 128;   // 64 / 256 measured in round 4: no difference
 // Copies a block's contiguous [nrows][rowf] slab between global memory and the LDS slab of row stride rowf + 1, 128 consecutive
 // words per step.  (row, column) of word e come from a multiply-high by the reciprocal of the run-time row length (exact for
 // the slab's few thousand words): a true division per word cost more than everything else the kernel does, and carrying

@@ -78,7 +78,7 @@ class RadegsIntegrateArgs(ctypes.Structure):
 # every symbol include/radegs.h declares
 EXPORTED_SYMBOLS = ("radegs_forward", "radegs_backward", "radegs_backward_from_sums", "radegs_mark_visible", "radegs_integrate", "radegs_sh_grad_from_views", "radegs_geometry_bytes", "radegs_image_bytes",
                     "radegs_binning_bytes", "radegs_debug_export", "radegs_forget_image", "radegs_last_error", "radegs_version", "radegs_profile_enable",
-                    "radegs_profile_select", "radegs_profile_stride", "radegs_binning_stats", "radegs_profile_num_stages", "radegs_profile_stage_name", "radegs_profile_collect",
+                    "radegs_profile_select", "radegs_profile_stride", "radegs_binning_stats", "radegs_reload_env", "radegs_last_forward_used_streams", "radegs_profile_num_stages", "radegs_profile_stage_name", "radegs_profile_collect",
                     # fused pre/post steps (bound in graphics_utils.py / gaussian_model_ops.py)
                     "radegs_normals_forward", "radegs_normals_backward", "radegs_normal_loss_scratch_bytes",
                     "radegs_normal_loss_forward", "radegs_normal_loss_backward", "radegs_normals_last_error",
@@ -170,6 +170,10 @@ def library():
         L.radegs_version.restype = ctypes.c_char_p
         L.radegs_binning_stats.restype = None
         L.radegs_binning_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+        L.radegs_reload_env.restype = None
+        L.radegs_reload_env.argtypes = []
+        L.radegs_last_forward_used_streams.restype = ctypes.c_int
+        L.radegs_last_forward_used_streams.argtypes = []
         L.radegs_profile_enable.restype = None
         L.radegs_profile_enable.argtypes = [ctypes.c_int]
         L.radegs_profile_select.restype = None
@@ -554,6 +558,17 @@ def binning_stats(reset=False):
     calls, misses = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
     library().radegs_binning_stats(ctypes.byref(calls), ctypes.byref(misses), int(bool(reset)))
     return int(calls.value), int(misses.value)
+
+
+def reload_env():
+    """Have the library read its RADEGS_* environment switches again (it reads them once, at first use)."""
+    library().radegs_reload_env()
+
+
+def last_forward_used_streams():
+    """The blend formulation of this thread's last forward: True = sub-tile entry streams, False = tile-wide kernels, None = none yet."""
+    v = library().radegs_last_forward_used_streams()
+    return None if v < 0 else bool(v)
 
 
 def profile_enable(on=True, only=None, every=1):

@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Gradient parity as an OBSERVED quantity: per BASELINE config and per tensor, how far the HIP backward is from the
+compiled reference's (oracle/_ref: the reference's own backward.cu on the host cores) -- and how far the REFERENCE IS FROM ITSELF when
+its float atomics land in another order (the same code run with a different number of OpenMP threads over its CUDA blocks).
+
+    python scripts/gpu_grad_parity.py [--configs 100k,100k_both,C2,C3,C4,C5] [--out gpurun_out/r05_grad_parity.json]
+
+Per tensor and pair of runs:  strict = fraction of elements inside 1e-5 abs + 1e-4 rel;  worst = max |a - b| / max |b| (the tensor's
+scale);  rms = rms(a - b) / max |b|.  Tensors: the eight returned gradients of the EXECUTED backward (the product's default) and the nine
+per-Gaussian sums between the two halves of the backward.  tests/test_gpu_vs_compiled_reference.py derives its acceptance band from the
+committed copy of this file (profiles/r05_grad_parity.json): k x the reference's own self-noise, DESIGN.md 7.4.
+Test infrastructure: imports oracle/ (the checker), never the other way round."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "rade-gs_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+ATOL, RTOL = 1e-5, 1e-4
+SUM_COLS = {"dL_dcolors": slice(0, 3), "dL_dts": slice(3, 4), "dL_dray_planes": slice(4, 6), "dL_dnormals": slice(6, 9),
+            "dL_dmeans2D": slice(9, 12), "dL_dconic": slice(12, 15), "dL_dopacity_raw": slice(15, 16)}
+SUM_COLS_COORD = {"dL_dview_points": slice(16, 19), "dL_dcamera_planes": slice(19, 25)}
+GRADS = ("dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dmeans3D", "dL_dscales", "dL_drotations")
+
+
+def stats(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    scale = float(np.abs(b).max()) + 1e-30
+    d = np.abs(a - b)
+    return {"strict": float((d <= ATOL + RTOL * np.abs(b)).mean()), "worst": float(d.max() / scale),
+            "rms": float(np.sqrt((d * d).mean()) / scale), "scale": scale}
+
+
+def scene_for(name):
+    from synth_scene import make_config, make_scene
+    if name == "100k":
+        return make_scene(100_000, 608, 342, sh_degree=3, mu_px=1.5, seed=7, kernel_size=0.0, require_coord=False, require_depth=True)
+    if name == "100k_both":
+        return make_scene(100_000, 608, 342, sh_degree=3, mu_px=1.5, seed=7, kernel_size=0.1, require_coord=True, require_depth=True)
+    return make_config(name)
+
+
+def reference_run(s, g, threads):
+    from gpu_util import reference_sums
+    from oracle import ref
+    from test_ref_parity import ref_for
+    ref.set_num_threads(threads)
+    r = ref_for(s)
+    r.forward()
+    r.backward(g["color"], g["coord"], g["mcoord"], g["depth"], g["mdepth"], g["alpha"], g["normal"])
+    grads = {k: np.array(v, copy=True) for k, v in r.grads().items() if v is not None}
+    sums = reference_sums(r.get, s.means3D.shape[0], s.require_coord).copy()
+    vis = np.array(r.get("radii") > 0, copy=True)
+    r.close()
+    return grads, sums, vis
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="100k,100k_both,C2,C3,C4,C5")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_grad_parity.json"))
+    args = ap.parse_args()
+    import diff_gaussian_rasterization._C as C
+    from gpu_util import HipRun, hip_sums_as_reference
+    from oracle import ref
+    from synth_scene import upstream_grads
+    assert ref.available(), "oracle/_ref/libradegs_ref.so is missing"
+    C.OPACITY_GRAD_INTENDED = False   # the executed backward: the product's default and what the reference runs
+    ncpu = os.cpu_count() or 8
+    report = {"_about": "see scripts/gpu_grad_parity.py; ref_vs_ref: the compiled reference with %d against %d host threads (another atomic order)" % (ncpu, max(2, ncpu // 3)),
+              "_tolerance": {"atol": ATOL, "rtol": RTOL}}
+    ref.set_exp("spec")
+    try:
+        for name in args.configs.split(","):
+            t0 = time.time()
+            s = scene_for(name)
+            g = upstream_grads(s, 7)
+            gA, sA, vis = reference_run(s, g, ncpu)
+            gB, sB, _ = reference_run(s, g, max(2, ncpu // 3))
+            h = HipRun(s, "cuda:0")
+            h.forward()
+            C.KEEP_ACC = True
+            try:
+                got = h.backward(g)
+                acc = C.LAST_ACC
+            finally:
+                C.KEEP_ACC = False
+                C.LAST_ACC = None
+            mine = hip_sums_as_reference(acc, s)
+            rec = {"P": int(s.means3D.shape[0]), "W": s.W, "H": s.H, "coord": bool(s.require_coord), "depth": bool(s.require_depth),
+                   "kernel_size": float(s.kernel_size), "streams": C.last_forward_used_streams(), "grads": {}, "sums": {}}
+            for k in GRADS:
+                if got.get(k) is None or k not in gA:
+                    continue
+                b = gA[k].reshape(got[k].shape)
+                rec["grads"][k] = {"hip_vs_ref": stats(got[k], b), "ref_vs_ref": stats(gB[k].reshape(b.shape), b)}
+            cols = dict(SUM_COLS)
+            if s.require_coord:
+                cols.update(SUM_COLS_COORD)
+            for k, sl in cols.items():
+                b = sA[vis][:, sl]
+                rec["sums"][k] = {"hip_vs_ref": stats(mine[vis][:, sl], b), "ref_vs_ref": stats(sB[vis][:, sl], b)}
+            rec["seconds"] = round(time.time() - t0, 1)
+            report[name] = rec
+            worst = max(v["hip_vs_ref"]["worst"] / max(v["ref_vs_ref"]["worst"], 1e-12) for v in list(rec["grads"].values()) + list(rec["sums"].values()))
+            print(f"{name}: {rec['seconds']} s; worst ratio hip/ref self-noise over all tensors: {worst:.2f}", flush=True)
+            for grp in ("grads", "sums"):
+                for k, v in rec[grp].items():
+                    print(f"   {grp[:-1]:4s} {k:18s} hip strict {v['hip_vs_ref']['strict']:.5f} worst {v['hip_vs_ref']['worst']:.2e} rms {v['hip_vs_ref']['rms']:.2e} | "
+                          f"ref self strict {v['ref_vs_ref']['strict']:.5f} worst {v['ref_vs_ref']['worst']:.2e} rms {v['ref_vs_ref']['rms']:.2e}", flush=True)
+            del h, got, acc, mine
+            torch.cuda.empty_cache()
+    finally:
+        ref.set_exp("libm")
+        ref.set_num_threads(1)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(report, open(args.out, "w"), indent=1)
+    print("wrote", args.out)
+
+
+if __name__ == "__main__":
+    main()

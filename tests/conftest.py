@@ -46,6 +46,20 @@ def _gradient_mode(request):
         C.OPACITY_GRAD_INTENDED = prev
 
 
+@pytest.fixture(autouse=True)
+def _library_switches(request):
+    """The library reads its RADEGS_* environment switches once (rg_launch.inc::Switches); a test that flipped them must not leak its
+    setting into the next one: GPU tests start and end with the switches re-read from the (by then restored) environment."""
+    gpu = request.node.get_closest_marker("gpu") is not None
+    C = None
+    if gpu:
+        import diff_gaussian_rasterization._C as C
+        C.reload_env()
+    yield
+    if C is not None:
+        C.reload_env()   # autouse fixtures are torn down after the test's own (monkeypatch has restored the environment by now)
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _build_test_infrastructure():
     """The oracle and the host-check harness are plain g++ builds (seconds)."""

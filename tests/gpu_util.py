@@ -33,6 +33,7 @@ class HipRun:
         self.cov3D = None if cov3D is None else cov3D.to(self.dev).clone().requires_grad_(True)
         self.rs = settings_for(s, self.dev, debug, scale_modifier)
         self.state = None
+        C.reload_env()   # the library reads its RADEGS_* switches once; tests flip them (monkeypatch.setenv) before building a HipRun
 
     def forward(self):
         """through the autograd operator; also captures the state buffers via a direct `_C` call"""

@@ -41,10 +41,6 @@ def test_committed_pmc_summaries_feed_the_bench_line():
 
 def test_binning_bytes_moved_counts_the_key_width():
     b = _bench()
-    small = b.binning_bytes_moved(1_000_000, 3_900_000, 8160, True)
-    os.environ["RADEGS_KEY16"] = "0"
-    try:
-        wide = b.binning_bytes_moved(1_000_000, 3_900_000, 8160, True)
-    finally:
-        del os.environ["RADEGS_KEY16"]
+    small = b.binning_bytes_moved(1_000_000, 3_900_000, 8160, True)       # 1080p: 16-bit tile keys
+    wide = b.binning_bytes_moved(1_000_000, 3_900_000, 70000, True) - 8 * (70000 - 8160)   # a grid above 65 536 tiles keeps 32-bit keys
     assert wide - small == (2 + 2 * 6 + 2) * 3_900_000               # emission 2 B, two sort passes x 6 B, ranges 2 B per instance

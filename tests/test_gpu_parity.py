@@ -211,28 +211,14 @@ def test_mark_visible():
     assert np.array_equal(got, orc.mark_visible(s.means3D, s.viewmatrix, s.projmatrix))
 
 
-@pytest.mark.parametrize("fwd_ppl,bwd_ppl", [(1, 2), (2, 4), (4, 2)])
-def test_pixels_per_lane_variants_agree(fwd_ppl, bwd_ppl, monkeypatch):
+@pytest.mark.parametrize("bwd_ppl", [2, 4])
+def test_pixels_per_lane_variants_agree(bwd_ppl, monkeypatch):
+    """the tile-wide backward exists with one wave per 16x8 strip (2 pixels per lane) and one wave per tile (4; chosen for heavy overdraw)"""
     monkeypatch.setenv("RADEGS_STREAMS", "0")   # these are variants of the tile-wide kernels
-    monkeypatch.setenv("RADEGS_FWD_PPL", str(fwd_ppl))
     monkeypatch.setenv("RADEGS_BWD_PPL", str(bwd_ppl))
     s = make_scene(3000, 200, 136, sh_degree=3, mu_px=4.0, seed=44, kernel_size=0.1, require_coord=True, require_depth=True, pose="random")
     o, _ = check_forward(s)
     check_backward(s, o, seed=44)
-
-
-@pytest.mark.parametrize("coord,depth", MODES)
-@pytest.mark.parametrize("fwd_grouped,bwd_grouped", [(4, 8), (8, 0), (0, 4)])
-def test_entry_stream_variants_agree(coord, depth, fwd_grouped, bwd_grouped, monkeypatch):
-    """Both blend kernels exist with one culled entry stream per wave (0), four (one per 16-lane row) and eight (one per 8 lanes);
-    every variant must pass the same parity checks, whatever the defaults are."""
-    monkeypatch.setenv("RADEGS_STREAMS", "0")   # these are variants of the tile-wide kernels
-    monkeypatch.setenv("RADEGS_GROUPED_FWD", str(fwd_grouped))
-    monkeypatch.setenv("RADEGS_GROUPED_BWD", str(bwd_grouped))
-    s = make_scene(4000, 203, 131, sh_degree=2, mu_px=3.0, seed=61, kernel_size=0.1, require_coord=coord, require_depth=depth, pose="random",
-                   bg=(0.3, 0.1, 0.7))
-    o, _ = check_forward(s)
-    check_backward(s, o, seed=61)
 
 
 @pytest.mark.parametrize("coord,depth", MODES)
@@ -249,47 +235,15 @@ def test_blend_paths_agree_with_oracle(coord, depth, streams, monkeypatch):
 
 
 @pytest.mark.parametrize("coord,depth", MODES)
-@pytest.mark.parametrize("merged,wn", [(1, 48), (1, 128), (0, 0)])
-def test_merged_stream_backward(coord, depth, merged, wn, monkeypatch):
-    """The stream backward exists with a per-tile LDS merge of the per-entry sums (blend_bwd_merged_kernel: windows of `wn` list
-    positions, one accumulator line per (tile, entry)) -- the default of the coord-map modes -- and without (one per (block, entry)) -- the
-    default of the others.  Both in every mode, lists several windows long, ragged image."""
+def test_stream_backward_long_lists(coord, depth, monkeypatch):
+    """The stream backward in every mode on lists many rounds long and a ragged image.  In the coord-map modes a (block, entry)'s 32-float
+    record leaves as two atomic instructions, one per 64-byte line (lane l: components l and 16 + l) -- first run on hardware in round 5
+    (profiles/r05_ab_linewise.txt), the default of those modes since."""
     monkeypatch.setenv("RADEGS_STREAMS", "1")
-    monkeypatch.setenv("RADEGS_BWD_MERGED", str(merged))
-    if wn:
-        monkeypatch.setenv("RADEGS_MERGE_WN", str(wn))
     s = make_scene(5000, 203, 131, sh_degree=2, mu_px=5.0, seed=64, kernel_size=0.1, require_coord=coord, require_depth=depth, pose="random",
                    bg=(0.3, 0.1, 0.7))
     o, _ = check_forward(s)
     check_backward(s, o, seed=64)
-
-
-if __import__("os").environ.get("RADEGS_TEST_UNVERIFIED") == "1":
-    # blend_bwd_streams_kernel<coord, ., ., LINEWISE> was written after round 4's GPU budget was spent (DESIGN.md 12): it is not a default,
-    # and its test only exists on request until it has passed on a GPU once
-    @pytest.mark.parametrize("depth", [False, True])
-    def test_linewise_coord_stream_backward(depth, monkeypatch):
-        """coord-map modes, unmerged stream backward with one atomic instruction per 64-byte line of the record (RADEGS_BWD_LINEWISE=1)"""
-        monkeypatch.setenv("RADEGS_STREAMS", "1")
-        monkeypatch.setenv("RADEGS_BWD_MERGED", "0")
-        monkeypatch.setenv("RADEGS_BWD_LINEWISE", "1")
-        s = make_scene(5000, 203, 131, sh_degree=2, mu_px=5.0, seed=64, kernel_size=0.1, require_coord=True, require_depth=depth,
-                       pose="random", bg=(0.3, 0.1, 0.7))
-        o, _ = check_forward(s)
-        check_backward(s, o, seed=64)
-
-    @pytest.mark.parametrize("grouped", [4, 0])
-    @pytest.mark.parametrize("depth", [False, True])
-    def test_linewise_coord_tile_wide_backward(depth, grouped, monkeypatch):
-        """coord-map modes, tile-wide backward: four streams per wave with line-wise atomics (RADEGS_GROUPED_BWD=4), one stream with the
-        reduction in two 16-component halves (0); both behind RADEGS_BWD_LINEWISE=1"""
-        monkeypatch.setenv("RADEGS_STREAMS", "0")
-        monkeypatch.setenv("RADEGS_GROUPED_BWD", str(grouped))
-        monkeypatch.setenv("RADEGS_BWD_LINEWISE", "1")
-        s = make_scene(4000, 203, 131, sh_degree=2, mu_px=3.0, seed=61, kernel_size=0.1, require_coord=True, require_depth=depth,
-                       pose="random", bg=(0.3, 0.1, 0.7))
-        o, _ = check_forward(s)
-        check_backward(s, o, seed=61)
 
 
 def test_entry_streams_heavy_overdraw_termination_and_ragged_image(monkeypatch):
@@ -313,18 +267,6 @@ def test_tile_wide_backward_after_stream_forward(monkeypatch):
     s = make_scene(5000, 200, 136, sh_degree=1, mu_px=2.0, seed=64, kernel_size=0.1, require_coord=False, require_depth=True, pose="random")
     o, _ = check_forward(s)
     check_backward(s, o, seed=64)
-
-
-@pytest.mark.parametrize("depth", [True, False])
-def test_half_row_stream_backward(monkeypatch, depth):
-    """blend_bwd_streams8_kernel (8 lanes x 4 pixels per block, the two half rows of a DPP row trade one sum so that every
-    (block, entry) still leaves as one full-line atomic): an alternative to the default 16-lane walk, same results."""
-    monkeypatch.setenv("RADEGS_STREAMS", "1")
-    monkeypatch.setenv("RADEGS_STREAMS_BWD8", "1")
-    s = make_scene(6000, 232, 168, sh_degree=2, mu_px=2.5, seed=65, kernel_size=0.1, require_coord=False, require_depth=depth, pose="random",
-                   bg=(0.1, 0.4, 0.7))
-    o, _ = check_forward(s)
-    check_backward(s, o, seed=65)
 
 
 def test_forward_is_deterministic_and_backward_stable():

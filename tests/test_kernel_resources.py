@@ -60,14 +60,14 @@ def find(kernels, *parts):
 
 # (substrings of the mangled name) -> (minimum waves per SIMD, maximum scratch bytes, maximum static LDS bytes)
 BUDGET = [
-    (("blend_fwd_streams_kernelILb0ELb1ELb0E",), 7, 0, 4608),      # C2 / C3 forward blend (depth mode)
-    (("blend_fwd_streams_kernelILb0ELb0ELb0E",), 7, 0, 4608),
-    (("blend_fwd_streams_kernelILb1ELb1ELb0E",), 4, 32, 8192),     # coord-map modes (forcing 5 / 6 waves spills); 32 B: one
-                                                                    # staged record row goes through scratch once per round of 16 entries
-    (("blend_bwd_streams_kernelILb0ELb1ELb0E",), 6, 0, 5120),      # the dominant kernel
-    (("blend_bwd_streams_kernelILb0ELb0ELb0E",), 6, 0, 5120),
-    (("blend_bwd_merged_kernelILb1ELb1ELi64E",), 4, 0, 16384),     # both maps: windows of 64 positions, ten workgroups per CU by LDS
-    (("blend_bwd_merged_kernelILb1ELb0ELi64E",), 4, 0, 16384),
+    (("blend_fwd_streams_kernelILb0ELb1EE",), 7, 0, 4608),      # C2 / C3 forward blend (depth mode)
+    (("blend_fwd_streams_kernelILb0ELb0EE",), 7, 0, 4608),
+    (("blend_fwd_streams_kernelILb1ELb1EE",), 4, 32, 8192),     # coord-map modes (forcing 5 / 6 waves spills); 32 B: one
+                                                                 # staged record row goes through scratch once per round of 16 entries
+    (("blend_bwd_streams_kernelILb0ELb1EE",), 6, 0, 5120),      # the dominant kernel
+    (("blend_bwd_streams_kernelILb0ELb0EE",), 6, 0, 5120),
+    (("blend_bwd_streams_kernelILb1ELb1EE",), 4, 0, 8704),      # coord-map modes: two 64-byte lines per (block, entry), one atomic instruction each
+    (("blend_bwd_streams_kernelILb1ELb0EE",), 4, 0, 8704),
     (("preprocess_fwd_kernelILb0E",), 6, 0, 0),
     (("preprocess_bwd_kernel",), 3, 16, 0),                          # dynamic LDS: the SH slab
     (("block_lists_kernel",), 8, 0, 256),
@@ -87,10 +87,9 @@ def test_hot_kernel_keeps_its_occupancy_step(code_objects, parts, min_waves, max
 
 
 def test_no_default_blend_or_binning_kernel_spills(code_objects):
-    """the kernels a default run launches; the scalar tile-wide backward (blend_bwd_kernel, RADEGS_BWD_IMPL=0), the half-row variant
-    and the coord-map stream kernels (a few bytes once per round, see BUDGET) are comparison builds / listed above"""
-    default = ("blend_fwd_kernel", "blend_bwd_packed_kernel", "blend_fwd_streams_kernelILb0", "blend_bwd_streams_kernelILb0",
-               "blend_bwd_merged_kernel", "scatter_kernel", "digit_histogram", "scan_rows", "gather_", "block_lists", "balance_blocks",
+    """every blend and binning kernel of the library but the coord-map stream forward (a few bytes once per round, see BUDGET)"""
+    default = ("blend_fwd_kernel", "blend_bwd_packed_kernel", "blend_fwd_streams_kernelILb0", "blend_bwd_streams_kernel",
+               "scatter_kernel", "digit_histogram", "scan_rows", "gather_", "block_lists", "balance_blocks",
                "emit_instances", "tile_ranges", "preprocess_fwd")
     spilling = {k: v[0]["scratch"] for k, v in code_objects.items() if v[0]["scratch"] and any(s in k for s in default)}
     assert not spilling, spilling
