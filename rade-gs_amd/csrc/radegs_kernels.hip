@@ -139,8 +139,11 @@ template <bool MASKS>
 __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32_t* idx_sorted, const uint32_t* offsets,
                                                             const uint32_t* tiles_touched, const float4* splat_a, const int* radii,
                                                             const uint32_t* rect, int gx, int gy, uint32_t* tile_keys, uint32_t* vals,
-                                                            uint32_t cap, uint32_t* ranges_to_clear, uint32_t* count_mirror, uint32_t seq, uint32_t* stream_tag, int key16) {
+                                                            uint32_t cap, uint32_t* ranges_to_clear, uint32_t* count_mirror, uint32_t seq, uint32_t* stream_tag, int key16,
+                                                            int mask_in_key, const unsigned long long* tile_sq_sum) {
   // key16: tile ids leave as 16-bit keys (grids of at most 65 536 tiles): the tile sort then moves a third less (radegs_sort.hip)
+  // mask_in_key (MASKS, scenes of 2^24 Gaussians and more, 32-bit keys): the block mask rides in the top byte of the KEY -- the tile sort
+  // only looks at the low tile bits -- and the value is the plain Gaussian index
   uint16_t* const tile_keys16 = reinterpret_cast<uint16_t*>(tile_keys);
   // cap: capacity of tile_keys/vals.  With exact allocation it equals num_rendered; in the speculative path (rg_launch.inc)
   // it is a prediction and instances beyond it are dropped here (the host detects the overflow and redoes the binning).
@@ -154,9 +157,15 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32
   }
   if (count_mirror && i == 0) {
     __hip_atomic_store(count_mirror, offsets[P - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(count_mirror + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // PIN_SEQ
+    const unsigned long long sq = tile_sq_sum ? *tile_sq_sum : 0ull;   // PIN_SQ_LO / PIN_SQ_HI (rg_launch.inc)
+    __hip_atomic_store(count_mirror + 6, (uint32_t)sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(count_mirror + 7, (uint32_t)(sq >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // PIN_SEQ; a stream forward publishes it later, together with the chunks its lists took (balance_blocks_kernel)
+    if (!MASKS) __hip_atomic_store(count_mirror + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  if (i == 0) *stream_tag = MASKS ? kStreamTag : 0u;   // does this image state hold entry streams?  (ImageState::stream_tag)
+  if (i == 0) {   // does this image state hold entry streams?  (ImageState::stream_tag; the chunk allocator and its overflow flag start at 0)
+    stream_tag[0] = MASKS ? kStreamTag : 0u; stream_tag[1] = 0u; stream_tag[3] = 0u;
+  }
   const int lane = threadIdx.x & 63;
   uint32_t idx = 0, ntiles = 0, off = 0;
   int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
@@ -199,7 +208,7 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32
       }
       for (int x = x0; x < x1; x++) {
         if (off < cap) {
-          uint32_t v = idx;
+          uint32_t v = idx, kmask = 0u;
           if constexpr (MASKS) {
             uint32_t mask = e.kind == 1 ? 0xFFu : 0u;
             if (e.kind == 2) {
@@ -207,9 +216,9 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32
 #pragma unroll
               for (int r = 0; r < 4; r++) mask |= ellipse_cols(hit[r], xl[r], xh[r], ua) << (2 * r);
             }
-            v |= mask << kMaskShift;
+            if (mask_in_key) kmask = mask << kMaskShift; else v |= mask << kMaskShift;
           }
-          if (key16) tile_keys16[off] = (uint16_t)(y * gx + x); else tile_keys[off] = (uint32_t)(y * gx + x);
+          if (key16) tile_keys16[off] = (uint16_t)(y * gx + x); else tile_keys[off] = (uint32_t)(y * gx + x) | kmask;
           vals[off] = v;
         }
         off++;
@@ -230,25 +239,28 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32
     for (uint32_t t = lane; t < g_n; t += 64) {
       const int ty = (int)(t / (uint32_t)g_w), tx = (int)(t - (uint32_t)ty * (uint32_t)g_w);
       if (g_off + t < cap) {
-        uint32_t v = g_idx;
-        if constexpr (MASKS)
-          v |= ellipse_block_mask(g_mx, g_my, g_cx, g_cy, g_cz, g_thr, (float)((g_x0 + tx) * 16), (float)((g_y0 + ty) * 16)) << kMaskShift;
-        if (key16) tile_keys16[g_off + t] = (uint16_t)((g_y0 + ty) * gx + (g_x0 + tx)); else tile_keys[g_off + t] = (uint32_t)((g_y0 + ty) * gx + (g_x0 + tx));
+        uint32_t v = g_idx, kmask = 0u;
+        if constexpr (MASKS) {
+          const uint32_t mask = ellipse_block_mask(g_mx, g_my, g_cx, g_cy, g_cz, g_thr, (float)((g_x0 + tx) * 16), (float)((g_y0 + ty) * 16)) << kMaskShift;
+          if (mask_in_key) kmask = mask; else v |= mask;
+        }
+        if (key16) tile_keys16[g_off + t] = (uint16_t)((g_y0 + ty) * gx + (g_x0 + tx)); else tile_keys[g_off + t] = (uint32_t)((g_y0 + ty) * gx + (g_x0 + tx)) | kmask;
         vals[g_off + t] = v;
       }
     }
   }
 }
 
+// key_mask: the bits of a key that are the tile id (32-bit keys of a scene of 2^24 Gaussians and more carry the block mask above them)
 template <class K>
-__global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const K* keys, uint2* ranges, const uint32_t* L_dev) {
+__global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const K* keys, uint2* ranges, const uint32_t* L_dev, uint32_t key_mask) {
   if (L_dev) L = (int)min((uint32_t)L, *L_dev);  // capacity launch, see emit_instances_kernel
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= L) return;
-  const uint32_t cur = keys[i];
+  const uint32_t cur = (uint32_t)keys[i] & key_mask;
   if (i == 0) ranges[cur].x = 0;
   else {
-    const uint32_t prev = keys[i - 1];
+    const uint32_t prev = (uint32_t)keys[i - 1] & key_mask;
     if (cur != prev) { ranges[prev].y = i; ranges[cur].x = i; }
   }
   if (i == L - 1) ranges[cur].y = L;
@@ -668,7 +680,7 @@ struct BlendFwdArgs {
   const float* bg;
   float* out_color; float* out_coord; float* out_mcoord; float* out_depth; float* out_mdepth; float* out_alpha; float* out_normal;
   uint32_t* n_contrib; float* accum_coord; float* accum_depth; float* normal_length;
-  const uint32_t* blk_count; uint32_t* blk_consumed; uint32_t* blk_chunks; const uint32_t* blk_order;   // sub-tile entry streams (rg_streams.inc)
+  const uint32_t* blk_count; const uint32_t* blk_base; uint32_t* blk_consumed; uint32_t* blk_chunks; const uint32_t* blk_order;   // sub-tile entry streams (rg_streams.inc)
 };
 
 // blockIdx -> work item such that each XCD (block b runs on XCD b % 8) owns a contiguous band.
@@ -893,7 +905,7 @@ struct BlendBwdArgs {
   float* acc;  // [P][REC] per-Gaussian sums, SplatAcc order
   const uint32_t* stream_tag;   // ImageState::stream_tag (stream kernels only)
   uint32_t* stream_err;         // mapped host word: set when stream_tag says this buffer holds no entry streams (may be nullptr)
-  const uint32_t* blk_consumed; const uint32_t* blk_chunks; const uint32_t* blk_order;   // sub-tile entry streams (rg_streams.inc)
+  const uint32_t* blk_base; const uint32_t* blk_consumed; const uint32_t* blk_chunks; const uint32_t* blk_order;   // sub-tile entry streams (rg_streams.inc)
 };
 
 // In: v[i] = this lane's partial sum of component i.  Out (return value): the wave-wide total of

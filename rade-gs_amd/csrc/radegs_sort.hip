@@ -247,10 +247,12 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* t
 // rectangles in scan order (the instance emission then reads them sequentially).
 __device__ __forceinline__ uint32_t rect_count(uint32_t r) { return ((r >> 16) & 255u) * (r >> 24); }
 
+// sq_part != nullptr: sq_part[block] = sum of (count^2) over the block's items; gather_scan_kernel's last block adds the partial sums up
+// (the launcher's splat-size statistic, rg_launch.inc::use_streams -- no atomics: 1 000 same-address atomics cost 10 us here).
 template <bool PACKED>
 __global__ void __launch_bounds__(kSortThreads) gather_block_sums_kernel(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ idx,
                                                                          uint32_t n, uint32_t* __restrict__ block_sums,
-                                                                         uint32_t* __restrict__ gathered) {
+                                                                         uint32_t* __restrict__ gathered, unsigned long long* __restrict__ sq_part) {
   // the block's 4096 items, striped over the threads (the sum does not care about the order): coalesced index loads and stores,
   // and all 16 dependent gathers of a thread in flight together
   const uint32_t base = blockIdx.x * (uint32_t)(kSortThreads * kScanItems) + threadIdx.x;
@@ -263,11 +265,22 @@ __global__ void __launch_bounds__(kSortThreads) gather_block_sums_kernel(const u
 #pragma unroll
   for (int k = 0; k < kScanItems; k++) v[k] = id[k] != 0xFFFFFFFFu ? vals[id[k]] : 0u;  // the only random gather
   uint32_t s = 0;
+  unsigned long long s2 = 0ull;
 #pragma unroll
   for (int k = 0; k < kScanItems; k++) {
     const uint32_t i = base + k * kSortThreads;
     if (i < n) gathered[i] = v[k];   // the scan pass re-reads it sequentially
-    s += PACKED ? rect_count(v[k]) : v[k];
+    const uint32_t c = PACKED ? rect_count(v[k]) : v[k];
+    s += c;
+    s2 += (unsigned long long)c * c;
+  }
+  if (sq_part) {
+    __shared__ unsigned long long w2[4];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s2 += __shfl_xor(s2, d);
+    if ((threadIdx.x & 63) == 0) w2[threadIdx.x >> 6] = s2;
+    __syncthreads();
+    if (threadIdx.x == 0) sq_part[blockIdx.x] = (w2[0] + w2[1]) + (w2[2] + w2[3]);
   }
   uint32_t total;
   block_exclusive_scan(s, &total);
@@ -276,7 +289,19 @@ __global__ void __launch_bounds__(kSortThreads) gather_block_sums_kernel(const u
 
 template <bool PACKED>
 __global__ void __launch_bounds__(kSortThreads) gather_scan_kernel(const uint32_t* __restrict__ gathered, uint32_t n,
-                                                                   const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ out) {
+                                                                   const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ out,
+                                                                   const unsigned long long* __restrict__ sq_part,
+                                                                   unsigned long long* __restrict__ sq_sum) {
+  if (sq_sum && blockIdx.x == gridDim.x - 1) {   // the last block also adds up gather_block_sums_kernel's partial sums of squares
+    __shared__ unsigned long long w2[4];
+    unsigned long long t = 0ull;
+    for (uint32_t j = threadIdx.x; j < gridDim.x; j += kSortThreads) t += sq_part[j];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) t += __shfl_xor(t, d);
+    if ((threadIdx.x & 63) == 0) w2[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) *sq_sum = (w2[0] + w2[1]) + (w2[2] + w2[3]);
+  }
   const uint32_t base = blockIdx.x * (uint32_t)(kSortThreads * kScanItems) + threadIdx.x * kScanItems;
   uint32_t v[kScanItems];
   uint32_t s = 0;
@@ -392,24 +417,28 @@ hipError_t radix_sort_pairs_u16(void* temp, size_t temp_bytes, const uint16_t* k
 }  // namespace rg
 
 namespace rg {
-size_t scan_temp_bytes(size_t n) {
-  return ((n + kSortThreads * kScanItems - 1) / (kSortThreads * kScanItems) + 1) * sizeof(uint32_t) + 512 + n * sizeof(uint32_t);
+size_t scan_temp_bytes(size_t n) {   // block sums (u32) + partial sums of squares (u64) per block, then the gathered copy
+  return ((n + kSortThreads * kScanItems - 1) / (kSortThreads * kScanItems) + 64) * (sizeof(uint32_t) + sizeof(unsigned long long)) + 1024 +
+         n * sizeof(uint32_t);
 }
 
 // out[i] = sum_{j <= i} vals[idx[j]]   (rasterizer_impl.cu:350's InclusiveSum, taken in depth order); idx == nullptr: identity
 // packed_out != nullptr: `vals` are packed tile rectangles, the scan runs over their tile counts and packed_out[i] receives
 // vals[idx[i]] (n words).
 hipError_t inclusive_scan_gather_u32(void* temp, size_t temp_bytes, const uint32_t* vals, const uint32_t* idx, uint32_t* out, size_t n,
-                                     hipStream_t stream, uint32_t* packed_out) {
+                                     hipStream_t stream, uint32_t* packed_out, unsigned long long* sq_sum) {
   if (n == 0) return hipSuccess;
   if (temp_bytes < scan_temp_bytes(n)) return hipErrorInvalidValue;
   const uint32_t nblocks = (uint32_t)((n + kSortThreads * kScanItems - 1) / (kSortThreads * kScanItems));
-  uint32_t* block_sums = static_cast<uint32_t*>(temp);
-  uint32_t* gathered = packed_out ? packed_out : block_sums + ((nblocks + 64) & ~63u);
-  if (packed_out) hipLaunchKernelGGL(gather_block_sums_kernel<true>, dim3(nblocks), dim3(kSortThreads), 0, stream, vals, idx, (uint32_t)n, block_sums, gathered);
-  else hipLaunchKernelGGL(gather_block_sums_kernel<false>, dim3(nblocks), dim3(kSortThreads), 0, stream, vals, idx, (uint32_t)n, block_sums, gathered);
-  if (packed_out) hipLaunchKernelGGL(gather_scan_kernel<true>, dim3(nblocks), dim3(kSortThreads), 0, stream, gathered, (uint32_t)n, block_sums, out);
-  else hipLaunchKernelGGL(gather_scan_kernel<false>, dim3(nblocks), dim3(kSortThreads), 0, stream, gathered, (uint32_t)n, block_sums, out);
+  const uint32_t nb64 = (nblocks + 64) & ~63u;
+  unsigned long long* sq_part = static_cast<unsigned long long*>(temp);                // [nb64] (8-byte aligned: first in the buffer)
+  uint32_t* block_sums = reinterpret_cast<uint32_t*>(sq_part + nb64);                  // [nb64]
+  uint32_t* gathered = packed_out ? packed_out : block_sums + nb64;
+  if (!sq_sum) sq_part = nullptr;
+  if (packed_out) hipLaunchKernelGGL(gather_block_sums_kernel<true>, dim3(nblocks), dim3(kSortThreads), 0, stream, vals, idx, (uint32_t)n, block_sums, gathered, sq_part);
+  else hipLaunchKernelGGL(gather_block_sums_kernel<false>, dim3(nblocks), dim3(kSortThreads), 0, stream, vals, idx, (uint32_t)n, block_sums, gathered, sq_part);
+  if (packed_out) hipLaunchKernelGGL(gather_scan_kernel<true>, dim3(nblocks), dim3(kSortThreads), 0, stream, gathered, (uint32_t)n, block_sums, out, sq_part, sq_sum);
+  else hipLaunchKernelGGL(gather_scan_kernel<false>, dim3(nblocks), dim3(kSortThreads), 0, stream, gathered, (uint32_t)n, block_sums, out, sq_part, sq_sum);
   return hipGetLastError();
 }
 }  // namespace rg

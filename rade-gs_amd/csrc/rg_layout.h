@@ -53,6 +53,8 @@ struct GeomState {
   uint32_t* idx_sorted;        // [P]
   uint32_t* offsets;           // [P] inclusive scan of tiles_touched in depth order
   uint32_t* rect_sorted;       // [P] packed tile rectangles in depth order (written by the scan's gather, read by the emission)
+  unsigned long long* tile_sq_sum;   // [1] sum over the Gaussians of (tiles touched)^2: with num_rendered the size of the splat the average
+                               // instance belongs to, which chooses between the two blend formulations (rg_launch.inc::use_streams)
   char* temp;                  // device-primitive temp storage
   size_t temp_bytes;
   size_t total;
@@ -69,6 +71,7 @@ struct GeomState {
     g.idx_sorted = c.take<uint32_t>(P);
     g.offsets = c.take<uint32_t>(P);
     g.rect_sorted = c.take<uint32_t>(P);
+    g.tile_sq_sum = c.take<unsigned long long>(2);
     g.temp = c.take<char>(temp_bytes);
     g.temp_bytes = temp_bytes;
     g.total = c.total();
@@ -102,15 +105,17 @@ struct BinState {
 // own exactly culled, depth-ordered sub-list of the tile's list.  Storage is an array of ROUND CHUNKS: one chunk = the 16
 // entries a block's 16 lanes stage at a time = 16 x {gaussian id, position in the tile list} followed by the 16 per-lane
 // contribution words the forward blend leaves for the backward (bit j / 16+j: the lane's first / second pixel blended
-// entry j of this round).  The chunks of (tile t, block b) start at chunk index
-//     8 * ((range.x[t] >> 4) + t) + b * ceil(n_t / 16)
-// which needs no counting pass: sum_{t' < t} ceil(n_t'/16) <= (range.x[t] >> 4) + t.
+// entry j of this round).  The chunks of a block are consecutive and start at chunk blk_base[tile * 8 + block]: block_counts_kernel
+// counts every list first and the lists are laid out back to back, sum_b ceil(n_b / 16) chunks per tile (round 5; rounds 2-4 reserved
+// the tile's whole list for every block and needed no count: 8 * ((R >> 4) + tiles + 1) chunks, which stays the capacity that can never
+// overflow -- stream_chunk_capacity_safe -- and is what a forward without a usage history allocates).
 constexpr int kMaskShift = 24;                       // entry streams: instance value = Gaussian index | block mask << 24 while it is sorted
 constexpr uint32_t kGidMask = (1u << kMaskShift) - 1u;
 constexpr int kBlocksPerTile = 8;
+constexpr int kListGridMax = 2048;   // workgroups of the two list-building kernels: fills the chip once (8 workgroups of 4 waves per CU)
 constexpr int kChunkWords = 48;   // 16 x uint2 + 16 x u32
 constexpr uint32_t kStreamTag = 0x53545247u;   // ImageState::stream_tag
-inline size_t stream_chunk_capacity(size_t R, size_t tiles) { return (size_t)kBlocksPerTile * ((R >> 4) + tiles + 1); }
+inline size_t stream_chunk_capacity_safe(size_t R, size_t tiles) { return (size_t)kBlocksPerTile * ((R >> 4) + tiles + 1); }
 
 struct ImageState {
   uint32_t* ranges;      // [2*tiles]  (start,end) per tile
@@ -118,16 +123,20 @@ struct ImageState {
   float* accum_coord;    // [3*H*W]
   float* accum_depth;    // [H*W]
   float* normal_length;  // [H*W]
-  // entry streams (only when stream_R != 0).  They live at the END of the image state so that every offset above and the
+  // entry streams (only when stream_chunks != 0).  They live at the END of the image state so that every offset above and the
   // bases below depend on (W, H) alone: the backward finds them without knowing the capacity the forward allocated for.
   uint32_t* blk_count;     // [8*tiles] entries in each block's list
+  uint32_t* blk_base;      // [8*tiles] first chunk of each block's list
+  uint32_t* wg_need;       // [kListGridMax] chunks the tiles of each list-building workgroup need (block_counts_kernel -> block_lists_kernel)
   uint32_t* blk_consumed;  // [8*tiles] entries of it the forward walked before all of the block's pixels had terminated
   uint32_t* blk_order;     // [8*tiles] block ids (tile*8 + block) in wave order: wave w of the blend kernels walks entries 4w..4w+3
   uint32_t* stream_tag;    // [4] word 0: kStreamTag when THIS forward wrote entry streams into this buffer, 0 when it did not (written by
-                           // the instance emission of every forward; the stream backward kernels refuse any other value)
-  uint32_t* blk_chunks;    // [stream_chunk_capacity(stream_R, tiles) * kChunkWords]
+                           // the instance emission of every forward; the stream backward kernels refuse any other value); word 1: chunks
+                           // the forward's lists need in all (block_lists_kernel; also when they exceed the capacity, so the host learns the
+                           // real need); word 3: set when they did not fit
+  uint32_t* blk_chunks;    // [stream_chunks * kChunkWords]
   size_t total;
-  static ImageState carve(void* buf, size_t W, size_t H, size_t stream_R = 0) {
+  static ImageState carve(void* buf, size_t W, size_t H, size_t stream_chunks = 0) {
     Carver c(buf);
     ImageState s;
     const size_t tiles = ((W + 15) / 16) * ((H + 15) / 16), N = W * H;
@@ -137,10 +146,12 @@ struct ImageState {
     s.accum_depth = c.take<float>(N);
     s.normal_length = c.take<float>(N);
     s.blk_count = c.take<uint32_t>(kBlocksPerTile * tiles);
+    s.blk_base = c.take<uint32_t>(kBlocksPerTile * tiles);
+    s.wg_need = c.take<uint32_t>(kListGridMax);
     s.blk_consumed = c.take<uint32_t>(kBlocksPerTile * tiles);
     s.blk_order = c.take<uint32_t>(kBlocksPerTile * tiles);
     s.stream_tag = c.take<uint32_t>(4);
-    s.blk_chunks = c.take<uint32_t>(stream_R ? stream_chunk_capacity(stream_R, tiles) * kChunkWords : 0);
+    s.blk_chunks = c.take<uint32_t>(stream_chunks * kChunkWords);
     s.total = c.total();
     return s;
   }

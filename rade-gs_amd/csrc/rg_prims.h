@@ -32,6 +32,6 @@ hipError_t radix_sort_pairs_u32_27(void* temp, size_t temp_bytes, const uint32_t
 hipError_t radix_sort_pairs_u16(void* temp, size_t temp_bytes, const uint16_t* keys_in, uint16_t* keys_out, const uint32_t* vals_in,
                                 uint32_t* vals_out, size_t n, int end_bit, hipStream_t stream, const uint32_t* n_dev = nullptr);
 hipError_t inclusive_scan_gather_u32(void* temp, size_t temp_bytes, const uint32_t* vals, const uint32_t* idx, uint32_t* out, size_t n,
-                                     hipStream_t stream, uint32_t* packed_out = nullptr);
+                                     hipStream_t stream, uint32_t* packed_out = nullptr, unsigned long long* sq_sum = nullptr);
 
 }  // namespace rg

@@ -43,6 +43,12 @@ CONFIGS = {
     "C4": dict(P=5_000_000, W=1920, H=1080, sh_degree=3, mu_px=1.5, require_coord=True, require_depth=False, seed=4),
     "C5": dict(P=500_000, W=3840, H=2160, sh_degree=3, mu_px=12.0, require_coord=False, require_depth=True, seed=5,
                low_opacity=True),
+    # not a BASELINE config: C2's size with the shape of a TRAINED scene (train.py:118-126 renders COLMAP reconstructions) -- a heavy-tailed
+    # footprint distribution (log-normal sigma 1.3 instead of 0.6, plus 2 % of splats of 64 px and more) and Gaussians clustered on 200
+    # blobs, so that tile-list lengths span more than an order of magnitude.  What the per-launch choice between the two blend
+    # formulations has to survive (bench.py --config C2H; profiles/r05_C2H_*).
+    "C2H": dict(P=1_000_000, W=1920, H=1080, sh_degree=3, mu_px=1.0, require_coord=False, require_depth=True, seed=11,
+                sigma_ln=1.3, big_frac=0.02, big_px=64.0, clusters=200),
 }
 
 
@@ -93,7 +99,10 @@ def _t(a):
 
 def make_scene(P, W, H, sh_degree=3, mu_px=1.5, seed=0, kernel_size=0.0, require_coord=False, require_depth=True,
                low_opacity=False, pose="identity", fovx_deg=60.0, bg=(0.0, 0.0, 0.0), near_cull_frac=0.02,
-               filter3d=True) -> Scene:
+               filter3d=True, sigma_ln=0.6, big_frac=0.0, big_px=64.0, clusters=0) -> Scene:
+    """sigma_ln: width of the log-normal footprint distribution; big_frac / big_px: that share of the splats gets a footprint of
+    big_px .. 3 big_px pixels (6 sigma) instead; clusters > 0: the Gaussians sit on that many blobs (centres uniform in the frustum, blob radius
+    3 .. 25 % of the blob's depth, blob populations log-normal) instead of filling the frustum uniformly."""
     gen = _Rng(seed)
     tanfovx = math.tan(math.radians(fovx_deg) * 0.5)
     tanfovy = tanfovx * H / W
@@ -125,10 +134,25 @@ def make_scene(P, W, H, sh_degree=3, mu_px=1.5, seed=0, kernel_size=0.0, require
     zz = np.maximum(np.abs(z), 0.3)  # lateral extent also for culled points
     x = zz * tanfovx * U(P, -1.1, 1.1)
     y = zz * tanfovy * U(P, -1.1, 1.1)
+    if clusters:
+        cz = U(clusters, 2.0, 10.0)
+        cx, cy = cz * tanfovx * U(clusters, -1.0, 1.0), cz * tanfovy * U(clusters, -1.0, 1.0)
+        rad = cz * np.exp(U(clusters, math.log(0.03), math.log(0.25)))
+        w = np.exp(1.0 * gen.randn(clusters))
+        member = np.searchsorted(np.cumsum(w / w.sum()), gen.rand(P)).clip(0, clusters - 1)
+        off = gen.randn(P, 3) * (rad[member] / 2.0)[:, None]
+        live = z > 0.2                                  # the near-cull share keeps its place in front of the near plane
+        x = np.where(live, cx[member] + off[:, 0], x)
+        y = np.where(live, cy[member] + off[:, 1], y)
+        z = np.where(live, np.maximum(cz[member] + off[:, 2], 0.5), z)
+        zz = np.maximum(np.abs(z), 0.3)
     cam_pts = np.stack([x, y, z], 1)
     means3D = (cam_pts - T) @ Rw2c  # = Rw2c^T (p - T), row-vector form
 
-    sigma_px = np.exp(math.log(mu_px) + 0.6 * gen.randn(P))
+    sigma_px = np.exp(math.log(mu_px) + sigma_ln * gen.randn(P))
+    if big_frac > 0:
+        big = gen.rand(P) < big_frac
+        sigma_px = np.where(big, big_px / 6.0 * np.exp(U(P, 0.0, math.log(3.0))), sigma_px)   # footprint ~ 6 sigma: big_px .. 3 big_px
     aniso = np.exp(0.5 * gen.randn(P, 3))
     scales = (zz * sigma_px / focal_x)[:, None] * aniso
     if low_opacity:

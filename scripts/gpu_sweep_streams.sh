@@ -12,7 +12,7 @@ P=400000
 for mu in 1.5 3 5 8 12; do
   for st in 1 0; do run "mu=$mu streams=$st" "RADEGS_STREAMS=$st" --points $P --mu-px $mu; done
 done
-P=1000000
-for mu in 1.5 3 5; do
-  for st in 1 0; do run "C4-like(coord) 1M mu=$mu streams=$st" "RADEGS_STREAMS=$st" --config C4 --points $P --mu-px $mu; done
+P=400000
+for mu in 1.5 3 5 8 12; do
+  for st in 1 0; do run "coord map mu=$mu streams=$st" "RADEGS_STREAMS=$st" --config C4 --points $P --mu-px $mu; done
 done

@@ -38,6 +38,7 @@ class HipRun:
     def forward(self):
         """through the autograd operator; also captures the state buffers via a direct `_C` call"""
         from diff_gaussian_rasterization import GaussianRasterizer
+        self.C.reload_env()
         r = GaussianRasterizer(self.rs)
         self.out = r(self.means3D, self.means2D, self.opacities, shs=self.shs, colors_precomp=self.colors, scales=self.scales,
                      rotations=self.rotations, cov3D_precomp=self.cov3D)
@@ -46,6 +47,7 @@ class HipRun:
     def forward_native(self):
         e = torch.Tensor([])
         rs = self.rs
+        self.C.reload_env()
         res = self.C.rasterize_gaussians(rs.bg, self.means3D.detach(), e if self.colors is None else self.colors.detach(),
                                          self.opacities.detach(), e if self.scales is None else self.scales.detach(),
                                          e if self.rotations is None else self.rotations.detach(), rs.scale_modifier,
@@ -63,6 +65,7 @@ class HipRun:
     def backward(self, g):
         color, radii, coord, mcoord, depth, mdepth, alpha, normal = self.out
         dev = self.dev
+        self.C.reload_env()
         loss = (color * g["color"].to(dev)).sum() + (alpha * g["alpha"].to(dev)).sum()
         loss = loss + (coord * g["coord"].to(dev)).sum() + (mcoord * g["mcoord"].to(dev)).sum()
         loss = loss + (depth * g["depth"].to(dev)).sum() + (mdepth * g["mdepth"].to(dev)).sum()
@@ -118,6 +121,7 @@ def backward_from_sums(h, sums):
     """HipRun `h` after forward_native(): the per-Gaussian half of the backward over `sums` (numpy [P, rec]) -> dict of numpy gradients."""
     import torch
     C, rs = h.C, h.rs
+    C.reload_env()
     e = torch.Tensor([])
     st = h.state
     out = C.backward_from_sums(torch.from_numpy(np.ascontiguousarray(sums, dtype=np.float32)).to(h.dev), h.means3D.detach(), st[8],

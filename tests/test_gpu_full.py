@@ -14,6 +14,7 @@ Properties that need no oracle (also run at full C4/C5 size):
   - alpha in [0, 1], color - T*bg >= 0, n_contrib <= tile list length;
   - linearity of the backward in the cotangents: grad(2*w) == 2*grad(w) within fp32 noise.
 """
+import math
 import os
 
 import numpy as np
@@ -173,3 +174,61 @@ def test_full_size_properties(name):
     s = make_config(name)
     _forward_checks(s, None)
     _backward_checks(s, None, CONFIGS[name]["seed"])
+
+
+def test_scene_of_more_than_2p24_gaussians_runs_through_the_entry_streams():
+    """17 M Gaussians (R ~ 45 M instances of small splats): more than the 24 bits a Gaussian index has next to the block mask in an
+    instance value, and with the worst-case reservation of rounds 2-4 more stream storage than RADEGS_STREAMS_MAX_MB allows -- both
+    used to switch such a scene silently to the slower tile-wide kernels.  Now the mask rides in the 32-bit tile
+    key and the lists are stored at their real size: the automatic choice is the entry streams, the first call (no usage history) may
+    still go tile-wide, the second runs the streams inside the default budget -- and both formulations return the same image (exact
+    contributor counts, maps within 1e-5 / 1e-4).  No oracle at this size: the two formulations check each other."""
+    import diff_gaussian_rasterization._C as C
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = torch.device("cuda:0")
+    P, W, H = 17_000_000, 1920, 1080
+    assert P > (1 << 24)
+    g = torch.Generator(device=dev).manual_seed(17)
+    tanfovx = math.tan(math.radians(60.0) * 0.5)
+    tanfovy = tanfovx * H / W
+    focal = W / (2 * tanfovx)
+    z = torch.rand(P, device=dev, generator=g) * 8 + 2
+    x = z * tanfovx * (torch.rand(P, device=dev, generator=g) * 2.2 - 1.1)
+    y = z * tanfovy * (torch.rand(P, device=dev, generator=g) * 2.2 - 1.1)
+    means = torch.stack([x, y, z], 1).contiguous()
+    sigma_px = torch.exp(math.log(0.8) + 0.5 * torch.randn(P, device=dev, generator=g))
+    scales = ((z * sigma_px / focal)[:, None] * torch.exp(0.3 * torch.randn(P, 3, device=dev, generator=g))).contiguous()
+    rot = torch.nn.functional.normalize(torch.randn(P, 4, device=dev, generator=g)).contiguous()
+    opac = torch.sigmoid(torch.randn(P, 1, device=dev, generator=g)).contiguous()
+    shs = torch.randn(P, 1, 3, device=dev, generator=g).contiguous()
+    eye = torch.eye(4, device=dev)
+    from synth_scene import projection_matrix
+    proj = torch.from_numpy(projection_matrix(0.01, 100.0, 2 * math.atan(tanfovx), 2 * math.atan(tanfovy)).T.astype(np.float32)).to(dev)
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=tanfovx, tanfovy=tanfovy, kernel_size=0.0, bg=torch.zeros(3, device=dev),
+                                       scale_modifier=1.0, viewmatrix=eye, projmatrix=proj.contiguous(), sh_degree=0, campos=torch.zeros(3, device=dev),
+                                       prefiltered=False, require_depth=True, require_coord=False, debug=False)
+
+    def render():
+        with torch.no_grad():
+            out = GaussianRasterizer(rs)(means, torch.zeros_like(means), opac, shs=shs, scales=scales, rotations=rot)
+        torch.cuda.synchronize()
+        return out, C.last_forward_used_streams()
+
+    try:
+        os.environ["RADEGS_STREAMS"] = "0"
+        C.reload_env()
+        ref, used = render()
+        assert used is False
+        os.environ.pop("RADEGS_STREAMS")
+        C.reload_env()
+        render()                       # first automatic call: may run without a usage history
+        out, used = render()           # from the second call on the lists are sized from the previous view
+        assert used is True, "a small-splat scene of 17 M Gaussians must run the entry streams by itself"
+    finally:
+        os.environ.pop("RADEGS_STREAMS", None)
+        C.reload_env()
+    assert torch.equal(out[1], ref[1])                                   # radii
+    assert int((ref[1] > 0).sum()) > 10_000_000
+    for k in (0, 4, 5, 6, 7):
+        a, b = out[k].cpu().numpy(), ref[k].cpu().numpy()
+        assert close(a, b).all(), (k, float(np.abs(a - b).max()))

@@ -7,6 +7,8 @@ of up to thousands of fp32 atomics whose order differs run to run (the reference
 SURVEY A18), so the gradient check allows the fp32 reordering error of the per-Gaussian
 accumulation on top of the tolerance and reports the fraction inside the strict bound.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -246,6 +248,17 @@ def test_stream_backward_long_lists(coord, depth, monkeypatch):
     check_backward(s, o, seed=64)
 
 
+@pytest.mark.parametrize("streams", [0, 1])
+def test_trained_scene_shape_both_paths(streams, monkeypatch):
+    """The shape of a trained scene (synth_scene CONFIGS["C2H"]: heavy-tailed footprints -- sub-pixel splats next to splats covering
+    dozens of tiles -- clustered on blobs, tile lists from empty to thousands of entries) through either blend formulation."""
+    monkeypatch.setenv("RADEGS_STREAMS", str(streams))
+    s = make_scene(40_000, 480, 270, sh_degree=3, mu_px=1.0, seed=11, kernel_size=0.0, require_coord=False, require_depth=True,
+                   sigma_ln=1.3, big_frac=0.02, big_px=48.0, clusters=30)
+    o, _ = check_forward(s)
+    check_backward(s, o, seed=11)
+
+
 def test_entry_streams_heavy_overdraw_termination_and_ragged_image(monkeypatch):
     """Forced entry streams on big splats: lists of hundreds of entries per block, rows of pixels that terminate early (their
     block stops consuming its list) next to rows that do not, partial rounds, tail tiles of a ragged image."""
@@ -416,7 +429,7 @@ def test_unproduced_maps_are_zero_call_after_call():
 
 
 def test_stream_byte_budget_falls_back_to_the_tile_wide_kernels(monkeypatch):
-    """RADEGS_STREAMS_MAX_MB: above the budget the launcher does not ask for entry-stream storage (~96 B per instance of capacity);
+    """RADEGS_STREAMS_MAX_MB: above the budget the launcher does not ask for entry-stream storage;
     the tile-wide kernels then run on the plain image state -- same results."""
     import diff_gaussian_rasterization._C as C
     monkeypatch.setenv("RADEGS_STREAMS_MAX_MB", "0")
@@ -424,6 +437,63 @@ def test_stream_byte_budget_falls_back_to_the_tile_wide_kernels(monkeypatch):
     o, h = check_forward(s)
     assert h.state[11].numel() == C.library().radegs_image_bytes(s.W, s.H)      # no stream storage behind the image state
     check_backward(s, o, seed=66)
+
+
+@pytest.mark.parametrize("coord,depth", [(False, True), (True, True)])
+def test_block_masks_in_the_tile_keys(coord, depth, monkeypatch):
+    """Scenes of 2^24 Gaussians and more cannot carry an instance's block mask next to the Gaussian index in the 32-bit value: it rides in
+    the top byte of a 32-bit tile key instead (the sort only looks at the low tile bits; tile_ranges masks it off; block_lists_kernel
+    <MASK_IN_KEY> reads it from the sorted keys).  RADEGS_MASK_IN_KEY=1 walks a small scene through that layout: same results."""
+    monkeypatch.setenv("RADEGS_STREAMS", "1")
+    monkeypatch.setenv("RADEGS_MASK_IN_KEY", "1")
+    s = make_scene(6000, 232, 168, sh_degree=2, mu_px=2.5, seed=67, kernel_size=0.1, require_coord=coord, require_depth=depth, pose="random")
+    o, _ = check_forward(s)
+    check_backward(s, o, seed=67)
+    s = make_scene(1500, 203, 131, sh_degree=1, mu_px=14.0, seed=93, kernel_size=0.1, require_coord=coord, require_depth=depth, pose="random",
+                   low_opacity=True)      # splats of more than 16 tiles: the cooperative emission path
+    check_forward(s)
+
+
+def test_entry_stream_storage_is_sized_from_the_previous_view_and_an_overflow_is_redone():
+    """The entry streams are stored compactly (block_lists_kernel counts, then takes exactly the chunks a tile's lists need); a
+    speculative forward sizes that storage from what the previous forward at this resolution used (+25 %).  A view whose lists need
+    far more -- same Gaussians, camera pulled in -- overflows it: the kernel drops the lists it cannot place and raises the flag, the
+    host redoes the forward with the capacity that cannot overflow.  Results equal the non-speculative path's, bit for bit; and
+    the image state of a steady view is far smaller than the worst-case reservation of rounds 2-4."""
+    import diff_gaussian_rasterization._C as C
+    from gpu_util import HipRun
+    s = make_scene(30000, 328, 248, sh_degree=1, mu_px=1.2, seed=71, kernel_size=0.0, require_coord=False, require_depth=True)
+    os.environ["RADEGS_STREAMS"] = "1"
+    try:
+        os.environ["RADEGS_SPECULATE"] = "0"
+        exact = [t.clone() for t in HipRun(s, _dev()).forward_native()[1:9]]
+        os.environ["RADEGS_SPECULATE"] = "1"
+        for _ in range(3):                           # seed the (device, W, H) history
+            h = HipRun(s, _dev()); st = h.forward_native()
+        for a, b in zip(st[1:9], exact):
+            assert torch.equal(a, b)
+        steady_bytes = st[11].numel()
+        R_far = st[0]
+        calls0, misses0 = C.binning_stats(reset=True)
+        assert calls0 >= 2 and misses0 == 0, (calls0, misses0)      # steady state: the history-sized storage fitted
+        os.environ["RADEGS_SPECULATE_CHUNKS"] = "40"                # storage for 40 chunks = 640 list entries: certain to overflow
+        h2 = HipRun(s, _dev()); st2 = h2.forward_native()
+        calls, misses = C.binning_stats()
+        assert calls == 1 and misses == 1, (calls, misses)          # the chunk prediction was too small: the forward was redone
+        for a, b in zip(st2[1:9], exact):
+            assert torch.equal(a, b)
+        h2.forward()
+        g = upstream_grads(s, 71)
+        assert all(np.isfinite(v).all() for v in h2.backward(g).values() if v is not None)
+        # compact storage: the steady view's image state stays well under the old worst-case reservation (8 x ceil(n/16) chunks of 192 B per tile)
+        tiles = ((s.W + 15) // 16) * ((s.H + 15) // 16)
+        old_reservation = 8 * ((int(R_far * 1.25) >> 4) + tiles + 1) * 192
+        plain = C.library().radegs_image_bytes(s.W, s.H)
+        assert steady_bytes - plain < 0.5 * old_reservation, (steady_bytes - plain, old_reservation)
+    finally:
+        for k in ("RADEGS_STREAMS", "RADEGS_SPECULATE", "RADEGS_SPECULATE_CHUNKS"):
+            os.environ.pop(k, None)
+        C.reload_env()
 
 
 @pytest.mark.gpu

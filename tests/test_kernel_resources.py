@@ -70,7 +70,8 @@ BUDGET = [
     (("blend_bwd_streams_kernelILb1ELb0EE",), 4, 0, 8704),
     (("preprocess_fwd_kernelILb0E",), 6, 0, 0),
     (("preprocess_bwd_kernel",), 3, 16, 0),                          # dynamic LDS: the SH slab
-    (("block_lists_kernel",), 8, 0, 256),
+    (("block_lists_kernelILb0E",), 8, 0, 256),
+    (("block_counts_kernelILb0E",), 8, 0, 512),
     (("balance_blocks_kernel",), 8, 0, 4096),
     (("emit_instances_kernelILb1E",), 6, 0, 0),
     (("tile_ranges_kernelItE",), 8, 0, 0),
@@ -89,7 +90,7 @@ def test_hot_kernel_keeps_its_occupancy_step(code_objects, parts, min_waves, max
 def test_no_default_blend_or_binning_kernel_spills(code_objects):
     """every blend and binning kernel of the library but the coord-map stream forward (a few bytes once per round, see BUDGET)"""
     default = ("blend_fwd_kernel", "blend_bwd_packed_kernel", "blend_fwd_streams_kernelILb0", "blend_bwd_streams_kernel",
-               "scatter_kernel", "digit_histogram", "scan_rows", "gather_", "block_lists", "balance_blocks",
+               "scatter_kernel", "digit_histogram", "scan_rows", "gather_", "block_lists", "block_counts", "balance_blocks",
                "emit_instances", "tile_ranges", "preprocess_fwd")
     spilling = {k: v[0]["scratch"] for k, v in code_objects.items() if v[0]["scratch"] and any(s in k for s in default)}
     assert not spilling, spilling
