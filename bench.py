@@ -140,7 +140,7 @@ def main():
     bucket = None
     if world > 1 or force_allreduce:  # the backward writes its gradients straight into the exchange buffers
         if args.exchange == "factored":
-            bucket = FactoredGradExchange(P, s.shs.shape[1], s.sh_degree, dev)
+            bucket = FactoredGradExchange(P, s.shs.shape[1], s.sh_degree, dev, timing=True)
         else:
             bucket = GradBucket(P, s.shs.shape[1], dev)
         C.set_grad_allocator(dev, bucket.allocator)
@@ -194,6 +194,8 @@ def main():
     # the dominant kernel is timed live on every 2nd step of the timed region (the event pair around it is a ~12 us stream bubble;
     # every 2nd step of a 9-view rotation still visits every view)
     C.profile_enable(True, only=dom, every=2 if (dom is not None and args.steps >= 8) else 1)   # no warm-up steps: every stage, in the timed region
+    if bucket is not None and hasattr(bucket, "collect_timing"):
+        bucket.collect_timing()      # drop the warm-up steps' exchange timings
     C.binning_stats(reset=True)
     Rs, vis = [], []
     # one event per step boundary on the launch stream (~2 us each, no bubble: nothing waits on them): the spans between them say what a
@@ -211,6 +213,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     spans = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    xch = bucket.collect_timing() if (bucket is not None and hasattr(bucket, "collect_timing")) else []
     peak_step_bytes = torch.cuda.max_memory_allocated(dev) - mem_before - sum(r.numel() * 4 for r in vis[:-1])
     C.profile_enable(False)
     spec_calls, spec_misses = C.binning_stats()
@@ -309,6 +312,11 @@ def main():
                               "consumed); reference_definition = 256 x entries each tile's walk reaches (SURVEY 8d)"},
             "valu_roofline": valu,
         }
+        if xch:   # N > 1 (or --force-allreduce): what the gradient exchange costs and how much of it the step waits for (view_parallel.py)
+            out["exchange_ms"] = round(sum(t[0] for t in xch) / len(xch), 4)
+            out["exchange_exposed_ms"] = round(sum(t[1] for t in xch) / len(xch), 4)
+            out["exchange_note"] = ("rank 0, mean over the timed steps, GPU clock: exchange_ms = first collective of the step issued (under the "
+                                    "backward) -> gradients ready; exchange_exposed_ms = the part after the backward's last kernel was queued")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_cpu, cfg["seed"])
         if (world == 1 and not launched and not args.no_other_configs and args.config == "C2" and args.flags == "config" and args.mode == "train"
@@ -373,7 +381,7 @@ def pair_evaluations(C, s, last_state, coord):
 
 # which stage of the bench line a kernel of the committed PMC pass belongs to (name fragments, profiles/*_pmc_per_kernel.json)
 _STAGE_OF = (("preprocess_fwd_kernel", "preprocess_fwd"), ("preprocess_bwd_kernel", "preprocess_bwd"), ("drgb_clamped", "preprocess_bwd"),
-             ("blend_fwd", "blend_fwd"), ("block_lists", "blend_fwd"), ("balance_blocks", "blend_fwd"), ("blend_bwd", "blend_bwd"),
+             ("blend_fwd", "blend_fwd"), ("block_lists", "blend_fwd"), ("block_counts", "blend_fwd"), ("balance_blocks", "blend_fwd"), ("blend_bwd", "blend_bwd"),
              ("digit_histogram", "binning"), ("scan_rows", "binning"), ("scatter_kernel", "binning"), ("gather_block_sums", "binning"),
              ("gather_scan", "binning"), ("emit_instances", "binning"), ("tile_ranges", "binning"))
 

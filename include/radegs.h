@@ -147,6 +147,14 @@ typedef struct RadegsBwdArgs {
    * the caller records an event there and starts its all-gather of these 12-byte rows on another stream, under that kernel. */
   void (*drgb_ready)(void* user);
   void* drgb_ready_user;
+  /* Optional, for the same caller: with grad_chunks >= 2 the per-Gaussian backward is queued as that many launches over consecutive
+   * ranges of Gaussians, and after each one `grads_ready(grads_ready_user, first, count)` is called ON THE HOST: once `stream` reaches
+   * that point, rows [first, first + count) of dL_dmean3D / dL_dopacity / dL_dscale / dL_drot (and of every other returned gradient)
+   * are final -- the caller records an event and starts that part of its all-reduce on another stream, under the launches that
+   * follow.  0 or 1: one launch, no call. */
+  int grad_chunks;
+  void (*grads_ready)(void* user, int first, int count);
+  void* grads_ready_user;
 } RadegsBwdArgs;
 
 /* `accum_alloc` provides the per-Gaussian accumulation scratch (64 or 128 B per Gaussian). */

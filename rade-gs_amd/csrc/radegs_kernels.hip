@@ -1233,6 +1233,7 @@ struct PreBwdArgs {
   int drgb_done;              // dL_drgb_clamped was already written by drgb_clamped_kernel (RadegsBwdArgs::drgb_ready)
   int acc_final;              // the records hold the reference's FINAL per-Gaussian sums (constant factors applied): radegs_backward_from_sums
   int vec_slab;               // the SH slab moves in 16-byte pieces (3M % 4 == 0, 3M <= 48, shs and dL_dsh 16-byte aligned)
+  int first_block;            // this launch covers the Gaussians from first_block * 128 on (RadegsBwdArgs::grad_chunks)
 };
 
 // dL/dRGB with the SH clamp mask applied, straight from the blend backward's sums (the first three floats of every accumulator
@@ -1285,7 +1286,7 @@ constexpr int kSlabVecs = 12;   // 16-byte pieces per thread: 128 rows x 48 floa
 __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const PreBwdArgs a) {
   extern __shared__ float sh_slab[];  // [128][3M+1]
   const int tid = threadIdx.x;
-  const int base = blockIdx.x * kPreBwdThreads;
+  const int base = ((int)blockIdx.x + a.first_block) * kPreBwdThreads;
   const int idx = base + tid;
   const int nrows = min(kPreBwdThreads, a.P - base);
   const int rowf = a.M * 3, stride = rowf + 1;

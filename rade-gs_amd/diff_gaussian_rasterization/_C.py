@@ -59,7 +59,8 @@ class RadegsBwdArgs(ctypes.Structure):
                 ("dL_dscale", ctypes.c_void_p), ("dL_drot", ctypes.c_void_p),
                 ("require_coord", ctypes.c_int), ("require_depth", ctypes.c_int), ("debug", ctypes.c_int),
                 ("dL_drgb_clamped", ctypes.c_void_p), ("opacity_grad_intended", ctypes.c_int),
-                ("drgb_ready", ctypes.c_void_p), ("drgb_ready_user", ctypes.c_void_p)]
+                ("drgb_ready", ctypes.c_void_p), ("drgb_ready_user", ctypes.c_void_p),
+                ("grad_chunks", ctypes.c_int), ("grads_ready", ctypes.c_void_p), ("grads_ready_user", ctypes.c_void_p)]
 
 
 class RadegsIntegrateArgs(ctypes.Structure):
@@ -132,6 +133,7 @@ SKIP_GRAD = object()
 # host as soon as the kernel that writes dL_drgb_clamped is queued -- before the per-Gaussian backward -- so that an all-gather of
 # those rows can run under that kernel (include/radegs.h::RadegsBwdArgs.drgb_ready).
 _READY_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+_GRADS_READY_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
 
 
 def library():
@@ -399,6 +401,19 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 except Exception as ex:  # noqa: BLE001 -- must not unwind through the C frame
                     ready_err.append(ex)
             ready_cb = _READY_FN(_ready)
+        # ... and may take the per-Gaussian backward in several launches, told after each one which rows are final (include/radegs.h:
+        # grad_chunks / grads_ready): its all-reduce of those rows then runs under the launches that follow
+        chunks_cb, nchunks = None, 0
+        if owner is not None and callable(getattr(owner, "grads_ready", None)) and int(getattr(owner, "grad_chunks", 0) or 0) > 1 \
+                and getattr(owner, "early_grads", False):
+            nchunks = int(owner.grad_chunks)
+
+            def _chunk(_user, first, count, _owner=owner):
+                try:
+                    _owner.grads_ready(int(first), int(count))
+                except Exception as ex:  # noqa: BLE001 -- must not unwind through the C frame
+                    ready_err.append(ex)
+            chunks_cb = _GRADS_READY_FN(_chunk)
         a = RadegsBwdArgs(P, int(degree), M, int(R), W, H, _ptr(bg), _ptr(m3), _ptr(shs), _ptr(col), _ptr(al), _ptr(sc), _ptr(rot),
                           _ptr(cov), _ptr(vm), _ptr(pm), _ptr(cp), float(scale_modifier), float(tan_fovx), float(tan_fovy),
                           float(kernel_size), _ptr(rad), _ptr(nm), _ptr(gb) if gb.numel() else None, _ptr(bb) if bb.numel() else None,
@@ -406,7 +421,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                           _ptr(g[6]), _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
                           _ptr(dL_dsh) if (M and dL_dsh is not None) else None, _ptr(dL_dscales), _ptr(dL_drotations),
                           int(bool(require_coord)), int(bool(require_depth)), int(bool(debug)), _ptr(drgb), int(bool(OPACITY_GRAD_INTENDED)),
-                          ctypes.cast(ready_cb, ctypes.c_void_p) if ready_cb is not None else None, None)
+                          ctypes.cast(ready_cb, ctypes.c_void_p) if ready_cb is not None else None, None,
+                          nchunks, ctypes.cast(chunks_cb, ctypes.c_void_p) if chunks_cb is not None else None, None)
         with torch.cuda.device(dev):
             rc = L.radegs_backward(ctypes.byref(a), acc.cb, None, _stream(dev))
         acc.release()
@@ -450,7 +466,7 @@ def backward_from_sums(sums, means3D, radii, colors, scales, rotations, scale_mo
                       _ptr(rad), None, _ptr(gb), None, None, None, None, None, None, None, None, None,
                       _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
                       _ptr(dL_dsh) if M else None, _ptr(dL_dscales), _ptr(dL_drotations), int(bool(require_coord)), 0, 0, None,
-                      int(bool(OPACITY_GRAD_INTENDED)), None, None)
+                      int(bool(OPACITY_GRAD_INTENDED)), None, None, 0, None, None)
     with torch.cuda.device(dev):
         rc = L.radegs_backward_from_sums(ctypes.byref(a), _ptr(sm), _stream(dev))
     _check(rc, "radegs_backward_from_sums")

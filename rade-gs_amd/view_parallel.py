@@ -112,23 +112,33 @@ class FactoredGradExchange:
         here    all-reduce  44 B + all-gather (N-1) * 12 B        = 161 B per Gaussian at N = 8
     The result equals the plain all-reduce up to fp32 summation order.  GPU only (the rebuild is a HIP kernel).
 
-    Overlap: the dL/dRGB rows are final one kernel before the rest of the backward (`drgb_ready`, called by the backward on the host
-    between the two kernels): their all-gather -- the larger share of the bytes at N = 8 -- is started there on a side stream and
-    runs under the per-Gaussian backward kernel; `exchange()` then only issues the 44-B all-reduce and waits.
+    Overlap, in the order the backward produces its results:
+      1. the dL/dRGB rows are final one kernel before the rest of the backward (`drgb_ready`, called by the backward on the host between
+         the two kernels): their all-gather -- the larger share of the bytes at N = 8 -- starts there on a side stream and runs under
+         the per-Gaussian backward;
+      2. the per-Gaussian backward is queued in `grad_chunks` launches over consecutive ranges of Gaussians (`grads_ready(first, count)`,
+         called after each launch is queued): the 44-B rows of a finished range are all-reduced under the launches that follow -- with
+         two chunks half of the all-reduce is hidden, only the last chunk's part (and the densification statistics, which exist only
+         after the backward) waits for the last kernel.
+    `exchange()` issues what is still missing and waits.  Every rank issues the same collectives in the same order.
 
-    Usage: `_C.set_grad_allocator(device, ex.allocator)` before the backward; `ex.set_view(campos)` if the all-gather should start
+    Usage: `_C.set_grad_allocator(device, ex.allocator)` before the backward; `ex.set_view(campos)` if the collectives should start
     early; `ex.exchange(means3D, campos)` after the backward."""
 
     SMALL = ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations")
 
-    def __init__(self, P: int, M: int, degree: int, device, group=None):
+    def __init__(self, P: int, M: int, degree: int, device, group=None, grad_chunks: int = 2, timing: bool = False):
         from diff_gaussian_rasterization import _C
         self._C, self.P, self.M, self.D, self.group = _C, P, M, degree, group
-        assert_same_on_all_ranks("(P, M, sh_degree)", (P, M, degree), group)
+        assert_same_on_all_ranks("(P, M, sh_degree, grad_chunks)", (P, M, degree, grad_chunks), group)
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         shapes = {"dL_dmeans3D": (P, 3), "dL_dopacity": (P, 1), "dL_dscales": (P, 3), "dL_drotations": (P, 4)}
         sizes = [int(torch.Size(shapes[k]).numel()) for k in self.SMALL]
-        self.small = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+        # one flat buffer: the four small gradient tensors, then the densification statistics of the view ([P, 3]: |grad xy|, |grad abs|,
+        # visible) -- summed over the ranks by the same collective type on the same stream, no second bucket
+        self.flat = torch.zeros(sum(sizes) + 3 * P, dtype=torch.float32, device=device)
+        self.small = self.flat[:sum(sizes)]
+        self.stats = self.flat[sum(sizes):].view(P, 3)
         self.views, off = {}, 0
         for k, n in zip(self.SMALL, sizes):
             self.views[k] = self.small[off:off + n].view(shapes[k])
@@ -139,36 +149,69 @@ class FactoredGradExchange:
         self.dL_dsh = torch.empty((P, M, 3), dtype=torch.float32, device=device)
         self.device = torch.device(device)
         self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-        self._early = None        # (handles, event) of an all-gather started from drgb_ready()
+        self._early = None        # handles of the all-gathers started from drgb_ready()
+        self._chunk_handles = []  # handles of the all-reduces started from grads_ready()
+        self._rows_done = 0       # rows of the small tensors whose all-reduce has been issued
         self._campos = None
+        self.grad_chunks = int(grad_chunks)
+        self.timing = bool(timing) and self.device.type == "cuda"
+        self._t_first = None      # event on the side stream before the step's first collective (timing)
+        self._timings = []        # (first collective issued, exchange() entered, exchange() done) event triples, one per step
 
     def set_view(self, campos):
-        """The camera position of the view about to be differentiated: lets drgb_ready() start the all-gathers early."""
+        """The camera position of the view about to be differentiated: lets drgb_ready() / grads_ready() start the collectives early."""
         self._campos = campos.reshape(1, 3).to(torch.float32).contiguous()
+
+    @property
+    def _early_ok(self):
+        if os.environ.get("RADEGS_EARLY_ALLGATHER", "1") == "0":     # escape hatch: issue every collective from exchange()
+            return False
+        return self._campos is not None and dist.is_available() and dist.is_initialized()
 
     @property
     def early_drgb(self):
         """True when the backward should write the dL/dRGB rows with their own early kernel and call drgb_ready()."""
-        if os.environ.get("RADEGS_EARLY_ALLGATHER", "1") == "0":     # escape hatch: issue every collective from exchange()
-            return False
-        return self._campos is not None and dist.is_available() and dist.is_initialized()
+        return self._early_ok
+
+    @property
+    def early_grads(self):
+        """True when the backward should queue its per-Gaussian kernel in grad_chunks launches and call grads_ready() after each."""
+        return self._early_ok and self.grad_chunks > 1
+
+    def _on_side_stream(self, issue):
+        """Run `issue()` (which starts asynchronous collectives) on the side stream, behind everything queued on the launch stream so far."""
+        if self._side is None:      # CPU tensors (gloo): asynchronous collectives need no stream
+            return issue()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ev)
+            if self.timing and self._t_first is None:
+                self._t_first = torch.cuda.Event(enable_timing=True)
+                self._t_first.record(self._side)
+            return issue()
 
     def drgb_ready(self):
         """Called by `_C.rasterize_gaussians_backward` on the host once the kernel that writes the dL/dRGB rows is queued (and the
         per-Gaussian backward is not yet): start their all-gather on the side stream."""
         if not self.early_drgb:
             return
-        if self._side is None:      # CPU tensors (gloo): asynchronous collectives need no stream
-            h1 = dist.all_gather_into_tensor(self.gathered.view(-1, 3), self.drgb, group=self.group, async_op=True)
-            h2 = dist.all_gather_into_tensor(self.campos_all, self._campos, group=self.group, async_op=True)
-        else:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(self._side):
-                self._side.wait_event(ev)
-                h1 = dist.all_gather_into_tensor(self.gathered.view(-1, 3), self.drgb, group=self.group, async_op=True)
-                h2 = dist.all_gather_into_tensor(self.campos_all, self._campos, group=self.group, async_op=True)
-        self._early = (h1, h2)
+        self._early = self._on_side_stream(lambda: (
+            dist.all_gather_into_tensor(self.gathered.view(-1, 3), self.drgb, group=self.group, async_op=True),
+            dist.all_gather_into_tensor(self.campos_all, self._campos, group=self.group, async_op=True)))
+
+    def _allreduce_rows(self, first, count):
+        """asynchronous all-reduces of rows [first, first + count) of the four small tensors (contiguous inside each tensor)"""
+        return [dist.all_reduce(self.views[k][first:first + count], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for k in self.SMALL]
+
+    def grads_ready(self, first, count):
+        """Called by the backward on the host after each launch of its per-Gaussian kernel (include/radegs.h: grads_ready): rows
+        [first, first + count) of the small gradient tensors are final once the launch stream reaches this point.  All but the last
+        range are all-reduced from here, under the launches that follow; the last one leaves with exchange()."""
+        if not self.early_grads or first != self._rows_done or first + count >= self.P:
+            return
+        self._chunk_handles += self._on_side_stream(lambda: self._allreduce_rows(first, count))
+        self._rows_done = first + count
 
     def allocator(self, name, shape, dtype, device):
         if name == "dL_drgb_clamped":
@@ -178,26 +221,68 @@ class FactoredGradExchange:
         v = self.views.get(name)
         return v if (v is not None and v.shape == torch.Size(shape)) else None
 
-    def exchange(self, means3D, campos, average: bool = True):
+    def exchange(self, means3D, campos, average: bool = True, stats=None, radii=None):
+        """Finish the step's exchange.  stats: optional (|grad xy| [P], |grad abs| [P], visible [P]) of this rank's view -- summed over the
+        ranks with the last part of the small bucket (scene/gaussian_model.py:743-747 keeps densification consistent this way);
+        radii: optional int32 [P], maximum over the ranks.  Returns the gradient dict (+ 'densify_stats' [P, 3] / 'radii_max')."""
         scale = 1.0
-        if dist.is_available() and dist.is_initialized():
+        t0 = None
+        if self.timing:
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record(torch.cuda.current_stream(self.device))
+        on = dist.is_available() and dist.is_initialized()
+        rmax = None
+        if on:
+            if stats is not None:
+                self.stats[:, 0].copy_(stats[0].reshape(-1)); self.stats[:, 1].copy_(stats[1].reshape(-1)); self.stats[:, 2].copy_(stats[2].reshape(-1))
             # output in the concatenated form (world*P, 3): the layout every backend's all_gather_into_tensor accepts
             if self._early is not None:      # started under the per-Gaussian backward (drgb_ready)
                 h1, h2 = self._early
-                self._early, self._campos = None, None
             else:
-                h1 = dist.all_gather_into_tensor(self.gathered.view(-1, 3), self.drgb, group=self.group, async_op=True)
-                h2 = dist.all_gather_into_tensor(self.campos_all, campos.reshape(1, 3).to(torch.float32).contiguous(), group=self.group, async_op=True)
-            dist.all_reduce(self.small, op=dist.ReduceOp.SUM, group=self.group)
-            h1.wait()
-            h2.wait()
+                h1, h2 = self._on_side_stream(lambda: (
+                    dist.all_gather_into_tensor(self.gathered.view(-1, 3), self.drgb, group=self.group, async_op=True),
+                    dist.all_gather_into_tensor(self.campos_all, campos.reshape(1, 3).to(torch.float32).contiguous(), group=self.group, async_op=True)))
+            first = self._rows_done          # rows not yet on their way (everything, without early chunks)
+
+            def rest():
+                hs = self._allreduce_rows(first, self.P - first) if first else [dist.all_reduce(self.small, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+                if stats is not None:
+                    hs.append(dist.all_reduce(self.stats, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                return hs
+            handles = self._chunk_handles + self._on_side_stream(rest)
+            if radii is not None:
+                rmax = radii.clone()
+                handles.append(dist.all_reduce(rmax, op=dist.ReduceOp.MAX, group=self.group, async_op=True))
+            self._early, self._campos, self._chunk_handles, self._rows_done = None, None, [], 0
+            for h in (h1, h2, *handles):
+                h.wait()
             if average and self.world > 1:
                 self.small /= self.world
                 scale = 1.0 / self.world
         else:
             self.gathered[0].copy_(self.drgb)
             self.campos_all[0].copy_(campos.reshape(3))
+            rmax = radii
+            if stats is not None:
+                self.stats[:, 0].copy_(stats[0].reshape(-1)); self.stats[:, 1].copy_(stats[1].reshape(-1)); self.stats[:, 2].copy_(stats[2].reshape(-1))
         self._C.sh_grad_from_views(means3D, self.campos_all, self.gathered, self.D, self.M, scale, out=self.dL_dsh)
         out = dict(self.views)
         out["dL_dsh"] = self.dL_dsh
+        if stats is not None:
+            out["densify_stats"] = self.stats
+        if radii is not None:
+            out["radii_max"] = rmax
+        if self.timing:
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record(torch.cuda.current_stream(self.device))
+            self._timings.append((self._t_first if self._t_first is not None else t0, t0, t1))
+            self._t_first = None
+        return out
+
+    def collect_timing(self):
+        """[(exchange_ms, exposed_ms)] of the exchange() calls since the last collect -- call after a device synchronisation (timing=True).
+        exchange: first collective of the step issued -> exchange() done, on the GPU's clock; exposed: exchange() entered -> done on the
+        launch stream, i.e. what the step waits for on top of the backward."""
+        out = [(first.elapsed_time(t1), t0.elapsed_time(t1)) for first, t0, t1 in self._timings]
+        self._timings = []
         return out

@@ -21,10 +21,10 @@ cd /tmp
 B="$GRAFT_REPO_ROOT/bench.py --config $CFG $EXTRA_ARGS"
 NOCPU=""; { [ "$CFG" != "C2" ] || [ -n "$SFX" ]; } && NOCPU="--no-cpu-baseline"
 python $B --steps 20 --warmup 10 $NOCPU > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 300 $OUT/bench.json
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python $B --steps 20 --warmup 10 --no-cpu-baseline > $OUT/rocprof_bench.log 2>&1; echo "rocprof rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python $B --steps 20 --warmup 10 --no-cpu-baseline --no-other-configs > $OUT/rocprof_bench.log 2>&1; echo "rocprof rc=$?"
 find $OUT/kt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
-timeout 300 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_tcc --output-format csv -- python $B --steps 9 --warmup 9 --no-cpu-baseline > $OUT/pmc_tcc.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVES -d $OUT/pmc_sq --output-format csv -- python $B --steps 9 --warmup 9 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_tcc --output-format csv -- python $B --steps 9 --warmup 9 --no-cpu-baseline --no-other-configs > $OUT/pmc_tcc.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVES -d $OUT/pmc_sq --output-format csv -- python $B --steps 9 --warmup 9 --no-cpu-baseline --no-other-configs > $OUT/pmc_sq.log 2>&1
 find $OUT -name "*counter_collection.csv" | while read f; do d=$(basename $(dirname $(dirname $f))); cp $f $OUT/${d}_counters.csv; done
 rm -rf $OUT/kt $OUT/pmc_tcc $OUT/pmc_sq
 ls $OUT

@@ -36,14 +36,14 @@ PY
       echo "pytest rc=$?"; tail -4 gpurun_out/${TAG}_pytest_$n.log ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/${TAG}_smoke.log ;;
     bench)
-      timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline $args > gpurun_out/${TAG}_bench_$n.log 2>&1
+      timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs $args > gpurun_out/${TAG}_bench_$n.log 2>&1
       tail -1 gpurun_out/${TAG}_bench_$n.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bench[$n] ${RADEGS_LIB:-intree} $args', d['value'], d['ms_per_step'], {k: round(v,4) for k,v in d['stages_ms'].items() if v})" 2>/dev/null || tail -3 gpurun_out/${TAG}_bench_$n.log ;;
     benchfull)
       timeout 900 python bench.py $args > gpurun_out/${TAG}_benchfull_$n.log 2>&1; tail -1 gpurun_out/${TAG}_benchfull_$n.log | cut -c1-400 ;;
     env) k=${arg%%=*}; v=${arg#*=}; if [ -z "$v" ]; then unset $k; else export $k="$v"; fi ;;
     ab) if [ "$arg" = base ]; then unset RADEGS_LIB; else export RADEGS_LIB=$PWD/gpurun_ab/libradegs_$arg.so; fi ;;
     prof)
-      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof_$n -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline $args > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof_$n.log 2>&1)
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof_$n -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs $args > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof_$n.log 2>&1)
       echo "prof rc=$?"; f=$(find gpurun_out/${TAG}_prof_$n -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" | cut -d, -f1-5 | cut -c1-150 ;;
     pmc) bash scripts/gpu_pmc.sh $args ;;
     py) s=${arg%%,*}; a=""; [ "$s" != "$arg" ] && a=${arg#*,}; timeout 1200 python scripts/$s ${a//,/ } > gpurun_out/${TAG}_py_$n.log 2>&1; echo "py $s rc=$?"; tail -12 gpurun_out/${TAG}_py_$n.log ;;

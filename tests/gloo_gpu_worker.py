@@ -51,9 +51,13 @@ def main():
             if early:
                 ex.set_view(mine.campos)
             _backward(C, mine, g, e)
-            got = ex.exchange(mine.means3D, mine.campos, average=True)
+            if early:      # the two-launch per-Gaussian backward: the first half's all-reduce was started from its hook
+                res["chunks_started"] = len(ex._chunk_handles) == 4 and 0 < ex._rows_done < P
+            got = ex.exchange(mine.means3D, mine.campos, average=True, stats=(torch.full((P,), float(rank + 1), device=dev),) * 3,
+                              radii=torch.full((P,), rank + 5, device=dev, dtype=torch.int32))
             torch.cuda.synchronize(dev)
             res["factored_early" if early else "factored"] = {k: rel(got[k], want[k]) for k in want}
+            res["folded_stats_ok"] = bool((got["densify_stats"] == float(sum(range(1, world + 1)))).all() and (got["radii_max"] == world + 4).all())
         bk = GradBucket(P, M, dev)
         C.set_grad_allocator(dev, bk.allocator)
         _backward(C, mine, g, e)

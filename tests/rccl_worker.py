@@ -53,9 +53,15 @@ def main():
         assert ex.early_drgb
         _backward(C, s, g, e)
         res["early_started"] = ex._early is not None
-        got = ex.exchange(s.means3D, s.campos, average=True)
+        # ... and the per-Gaussian backward queued in two launches: the first half's 44-B rows are on their way under the second launch
+        res["chunks_started"] = len(ex._chunk_handles) == 4 and 0 < ex._rows_done < P
+        st = (plain[0][:, :2].norm(dim=1), plain[0][:, 2].abs(), (plain[0][:, 2] != 0).float())
+        rr = torch.arange(P, device=dev, dtype=torch.int32)
+        got = ex.exchange(s.means3D, s.campos, average=True, stats=st, radii=rr)
         torch.cuda.synchronize(dev)
         res["factored_early"] = {k: rel(got[k], want[k]) for k in want}
+        res["folded_stats_ok"] = bool(torch.equal(got["densify_stats"][:, 0], st[0]) and torch.equal(got["densify_stats"][:, 2], st[2])
+                                      and torch.equal(got["radii_max"], rr))
         # 2. plain bucket: one all-reduce of 236 B/Gaussian written in place by the backward
         bk = GradBucket(P, M, dev)
         C.set_grad_allocator(dev, bk.allocator)

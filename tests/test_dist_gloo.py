@@ -157,6 +157,22 @@ def _factored_worker(rank, world, port, out_dir):
     for k in out:
         assert torch.equal(out_early[k], out[k]), k
     assert ex._early is None and not ex.early_drgb
+    # ... and with the small bucket leaving in two parts, the way the backward's grads_ready hook sends it (rows of the first launch
+    # while the second is queued), plus the densification statistics in the same bucket and the radii maximum
+    ex.set_view(campos)
+    assert ex.early_grads and ex.grad_chunks == 2
+    ex.drgb_ready()
+    ex.small.copy_(small_before)
+    ex.grads_ready(0, 128)                       # first launch done: its rows are on their way
+    assert len(ex._chunk_handles) == 4 and ex._rows_done == 128
+    ex.grads_ready(128, P - 128)                 # the last range leaves with exchange()
+    assert ex._rows_done == 128
+    out_chunked = ex.exchange(means3D, campos, average=True, stats=(torch.full((P,), float(rank + 1)),) * 3,
+                              radii=torch.full((P,), rank + 5, dtype=torch.int32))
+    for k in out:
+        assert torch.equal(out_chunked[k], out[k]), k
+    assert bool((out_chunked["densify_stats"] == float(sum(range(1, world + 1)))).all()) and bool((out_chunked["radii_max"] == world + 4).all())
+    assert ex._chunk_handles == [] and ex._rows_done == 0
     torch.save({"out": {k: v.clone() for k, v in out.items()}, "small": small_before, "drgb": drgb, "campos": campos, "means3D": means3D},
                os.path.join(out_dir, f"f{rank}.pt"))
     dist.barrier()

@@ -46,6 +46,8 @@ def test_exchange_collectives_run_through_rccl_and_match_the_plain_backward(tmp_
             # selects the intended derivative, so no slip-term noise rides on the geometry gradients)
             assert v <= (2e-5 if k in ("dL_dsh", "dL_dopacity") else 1e-3), (mode, k, v)
     assert res["stats_ok"]
+    assert res["chunks_started"]         # ... and grads_ready(): the first half of the 44-B rows left under the second per-Gaussian launch
+    assert res["folded_stats_ok"]        # densification statistics ride in the same bucket; radii take the maximum
 
 
 @pytest.mark.parametrize("exchange", ["factored", "allreduce"])
@@ -74,3 +76,4 @@ def test_two_ranks_share_one_gpu_through_gloo(tmp_path):
         for mode in ("factored", "factored_early", "bucket"):
             for k, v in res[mode].items():
                 assert v <= (2e-5 if k in ("dL_dsh", "dL_dopacity") else 1e-3), (rank, mode, k, v)
+        assert res["chunks_started"] and res["folded_stats_ok"], res    # two-launch per-Gaussian backward + statistics in the bucket, across two real ranks
