@@ -32,7 +32,7 @@ print("cold: %d processes, %d clean, first_on_box in %d, mismatches: %s" % (len(
 PY
       ;;
     pytest)
-      if [ -n "$arg" ]; then timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider -k "$args" > gpurun_out/${TAG}_pytest_$n.log 2>&1; else timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/${TAG}_pytest_$n.log 2>&1; fi
+      if [ -n "$arg" ]; then timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=25 -k "$args" > gpurun_out/${TAG}_pytest_$n.log 2>&1; else timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=25 > gpurun_out/${TAG}_pytest_$n.log 2>&1; fi
       echo "pytest rc=$?"; tail -4 gpurun_out/${TAG}_pytest_$n.log ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/${TAG}_smoke.log ;;
     bench)
