@@ -131,10 +131,9 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* m
 constexpr int kEmitCoopThreshold = 16;
 // rect != nullptr (tile grid at most 255x255): rect[i] is the packed tile rectangle of the i-th Gaussian IN DEPTH ORDER (the scan's
 // gather wrote it): no random access at all here, instead of recomputing the rectangle from three gathers.
-// MASKS (sub-tile entry streams, rg_streams.inc; P < 2^24): the instance value also carries, in its top byte, which of the tile's
-// eight 8x4 blocks the splat can reach (ellipse_tile_mask, rg_blend.h).  Here the splat's record is in registers once for all its
-// tiles and the x-extent of its ellipse over a block row is shared by the tiles of a tile row; after the sort the same question
-// costs a dependent gather per list entry.  block_lists_kernel strips the byte again.
+// MASKS (sub-tile entry streams, rg_streams.inc): the instance value also carries, in its top byte, which of the tile's eight 8x4
+// blocks the splat can reach (ellipse_tile_mask, rg_blend.h).  Here the splat's record is in registers once for all its tiles; after
+// the sort the same question costs a dependent gather per list entry.  block_lists_kernel strips the byte again.
 template <bool MASKS>
 __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32_t* idx_sorted, const uint32_t* offsets,
                                                             const uint32_t* tiles_touched, const float4* splat_a, const int* radii,
@@ -188,38 +187,70 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32
       }
     }
   }
-  const bool big = ntiles > (uint32_t)kEmitCoopThreshold;
-  if (ntiles && !big) {
-    EllipseSetup e;
-    e.kind = 1;
-    if constexpr (MASKS) {
+  if constexpr (MASKS) {
+    // Entry streams: every INSTANCE gets a block mask (~150 instructions), and a lane that walks its own splat's tiles leaves most of
+    // the wave idle (a wave costs its LARGEST splat: 2x2 tiles next to 4x4).  The wave therefore expands its 64 splats into their
+    // instances and deals those to the lanes 64 at a time: exclusive prefix of the tile counts, lane t of a chunk finds its splat by a
+    // binary search over the prefixes (6 ds_bpermute steps), fetches that splat's rectangle and its ellipse set-up (computed once, by
+    // the owning lane, for the whole rectangle) and evaluates ONE tile: 4 slabs, 2 columns each.  Same instances at the same positions
+    // (offset of the splat + row-major position in its rectangle).
+    uint32_t incl = ntiles;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(incl, d);
+      if (lane >= d) incl += y;
+    }
+    const uint32_t excl = incl - ntiles;
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const int w_own = x1 - x0;
+    EllipseSetup e_own;
+    e_own.kind = 0; e_own.cy = 0.f; e_own.det = 0.f; e_own.cxM = 0.f; e_own.icx = 0.f; e_own.hx = 0.f; e_own.hy = 0.f; e_own.tstar = 0.f; e_own.eps = 0.f;
+    if (ntiles) {
       const float U = fmaxf(fabsf((float)(x0 * 16) - q0.x), fabsf((float)(x1 * 16 - 1) - q0.x));
       const float V = fmaxf(fabsf((float)(y0 * 16) - q0.y), fabsf((float)(y1 * 16 - 1) - q0.y));
-      e = ellipse_setup(q0.x, q0.y, q0.z, q0.w, q1.x, q1.z, U, V);
+      e_own = ellipse_setup(q0.x, q0.y, q0.z, q0.w, q1.x, q1.z, U, V);
     }
-    for (int y = y0; y < y1; y++) {
-      float xl[4] = {0.f, 0.f, 0.f, 0.f}, xh[4] = {0.f, 0.f, 0.f, 0.f};
-      bool hit[4] = {false, false, false, false};
-      if constexpr (MASKS) {
-        if (e.kind == 2) {
+    for (uint32_t base = 0; base < total; base += 64) {
+      const uint32_t t = base + (uint32_t)lane;
+      int g = 0;                                   // largest lane k with excl_k <= t (excl is non-decreasing, excl_0 = 0)
 #pragma unroll
-          for (int r = 0; r < 4; r++) hit[r] = ellipse_slab(e, (float)(y * 16 + 4 * r) - q0.y, xl[r], xh[r]);
+      for (int step = 32; step > 0; step >>= 1) {
+        const uint32_t pm = __shfl(excl, g + step);
+        if (pm <= t) g += step;
+      }
+      const uint32_t local = t - __shfl(excl, g);
+      const uint32_t g_idx = __shfl(idx, g), g_off = __shfl(off, g);
+      const int g_x0 = __shfl(x0, g), g_y0 = __shfl(y0, g), g_w = __shfl(w_own, g);
+      const float g_mx = __shfl(q0.x, g), g_my = __shfl(q0.y, g);
+      EllipseSetup e;
+      e.kind = __shfl(e_own.kind, g); e.cy = __shfl(e_own.cy, g); e.det = __shfl(e_own.det, g); e.cxM = __shfl(e_own.cxM, g);
+      e.icx = __shfl(e_own.icx, g); e.hx = __shfl(e_own.hx, g); e.hy = __shfl(e_own.hy, g); e.tstar = __shfl(e_own.tstar, g);
+      e.eps = __shfl(e_own.eps, g);
+      if (t < total) {
+        // row-major position in the splat's rectangle: local = ty * w + tx (local < 2^24: exact in float; the quotient is corrected by one)
+        uint32_t ty = (uint32_t)((float)local * __builtin_amdgcn_rcpf((float)g_w));
+        int tx = (int)local - (int)(ty * (uint32_t)g_w);
+        if (tx < 0) { ty--; tx += g_w; } else if (tx >= g_w) { ty++; tx -= g_w; }
+        const uint32_t pos = g_off + local;
+        if (pos < cap) {
+          const uint32_t mask = ellipse_tile_mask(e, (float)((g_x0 + tx) * 16) - g_mx, (float)((g_y0 + (int)ty) * 16) - g_my) << kMaskShift;
+          const uint32_t tile = (uint32_t)((g_y0 + (int)ty) * gx + (g_x0 + tx));
+          if (key16) tile_keys16[pos] = (uint16_t)tile; else tile_keys[pos] = tile | (mask_in_key ? mask : 0u);
+          vals[pos] = mask_in_key ? g_idx : (g_idx | mask);
         }
       }
+    }
+    return;
+  }
+  // tile-wide kernels: no masks.  Splats with few tiles are written by their own lane; a splat with many tiles (heavy-overdraw scenes:
+  // hundreds per splat) is handed to the whole wave, which writes its instances 64 at a time to consecutive addresses.
+  const bool big = ntiles > (uint32_t)kEmitCoopThreshold;
+  if (ntiles && !big) {
+    for (int y = y0; y < y1; y++) {
       for (int x = x0; x < x1; x++) {
         if (off < cap) {
-          uint32_t v = idx, kmask = 0u;
-          if constexpr (MASKS) {
-            uint32_t mask = e.kind == 1 ? 0xFFu : 0u;
-            if (e.kind == 2) {
-              const float ua = (float)(x * 16) - q0.x;
-#pragma unroll
-              for (int r = 0; r < 4; r++) mask |= ellipse_cols(hit[r], xl[r], xh[r], ua) << (2 * r);
-            }
-            if (mask_in_key) kmask = mask << kMaskShift; else v |= mask << kMaskShift;
-          }
-          if (key16) tile_keys16[off] = (uint16_t)(y * gx + x); else tile_keys[off] = (uint32_t)(y * gx + x) | kmask;
-          vals[off] = v;
+          if (key16) tile_keys16[off] = (uint16_t)(y * gx + x); else tile_keys[off] = (uint32_t)(y * gx + x);
+          vals[off] = idx;
         }
         off++;
       }
@@ -231,21 +262,11 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32
     todo &= todo - 1;
     const uint32_t g_idx = __shfl(idx, src), g_n = __shfl(ntiles, src), g_off = __shfl(off, src);
     const int g_x0 = __shfl(x0, src), g_y0 = __shfl(y0, src), g_w = __shfl(x1, src) - g_x0;
-    float g_mx = 0.f, g_my = 0.f, g_cx = 0.f, g_cy = 0.f, g_cz = 0.f, g_thr = 0.f;
-    if constexpr (MASKS) {
-      g_mx = __shfl(q0.x, src); g_my = __shfl(q0.y, src); g_cx = __shfl(q0.z, src); g_cy = __shfl(q0.w, src);
-      g_cz = __shfl(q1.x, src); g_thr = __shfl(q1.z, src);
-    }
     for (uint32_t t = lane; t < g_n; t += 64) {
       const int ty = (int)(t / (uint32_t)g_w), tx = (int)(t - (uint32_t)ty * (uint32_t)g_w);
       if (g_off + t < cap) {
-        uint32_t v = g_idx, kmask = 0u;
-        if constexpr (MASKS) {
-          const uint32_t mask = ellipse_block_mask(g_mx, g_my, g_cx, g_cy, g_cz, g_thr, (float)((g_x0 + tx) * 16), (float)((g_y0 + ty) * 16)) << kMaskShift;
-          if (mask_in_key) kmask = mask; else v |= mask;
-        }
-        if (key16) tile_keys16[g_off + t] = (uint16_t)((g_y0 + ty) * gx + (g_x0 + tx)); else tile_keys[g_off + t] = (uint32_t)((g_y0 + ty) * gx + (g_x0 + tx)) | kmask;
-        vals[g_off + t] = v;
+        if (key16) tile_keys16[g_off + t] = (uint16_t)((g_y0 + ty) * gx + (g_x0 + tx)); else tile_keys[g_off + t] = (uint32_t)((g_y0 + ty) * gx + (g_x0 + tx));
+        vals[g_off + t] = g_idx;
       }
     }
   }

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Per-seed record of the randomised parity sweep at the STANDARD gradient criteria (0.99 strict fraction / 1x band / 1.1x rms /
 1.25x max against the fp64 arbiter), for the seeds of tests/test_gpu_fuzz.py and beyond: which tensor fails which criterion by how
-much.  Run on the GPU box; with RADEGS_LIB pointing at the RADEGS_BWD_EXACT build (specified exponential + IEEE division in the
-stream backward) the same seeds show whether a failure is arithmetic (it vanishes) or summation order (it stays).
+much.  Run on the GPU box.  (Round 3 ran the same seeds on a -DRADEGS_BWD_EXACT build -- specified exponential + IEEE division in the stream
+backward -- to separate arithmetic from summation order: the failures stayed, profiles/r03_fuzz_table_exact_arithmetic_backward.txt; that
+build hook was removed with the other experiment hooks in round 5.)
 
     python scripts/gpu_fuzz_table.py 0:40 > gpurun_out/fuzz_table.txt
 """

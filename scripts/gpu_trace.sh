@@ -5,7 +5,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/trace
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-timeout 240 rocprofv3 --kernel-trace -d $OUT/kt --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no-cpu-baseline > $OUT/log.txt 2>&1; echo "trace rc=$?"
+timeout 240 rocprofv3 --kernel-trace -d $OUT/kt --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-other-configs > $OUT/log.txt 2>&1; echo "trace rc=$?"
 find $OUT/kt -name "*kernel_trace.csv" -exec cp {} $OUT/kernel_trace.csv \;
 rm -rf $OUT/kt
 python3 - <<'PY'
