@@ -145,6 +145,31 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_device():
     assert L.radegs_backward(ctypes.byref(b), cb, None, None) == INVALID and "gradient outputs missing" in L.radegs_last_error().decode()
     b.P = 0
     assert L.radegs_backward(ctypes.byref(b), cb, None, None) == 0
+    # radegs_backward_from_sums (the per-Gaussian half over caller-supplied sums): everything its kernel dereferences is checked, and the
+    # 16-byte alignment its record loads need
+    L.radegs_backward_from_sums.restype = ctypes.c_int
+    L.radegs_backward_from_sums.argtypes = [ctypes.POINTER(C.RadegsBwdArgs), ctypes.c_void_p, ctypes.c_void_p]
+    s_ = C.RadegsBwdArgs()
+    s_.P, s_.D, s_.M, s_.width, s_.height = 3, 0, 1, 32, 32
+    s_.geom_buffer = fake
+    for f in ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dscale", "dL_drot"):
+        setattr(s_, f, fake)
+    def from_sums(sums=fake):
+        return L.radegs_backward_from_sums(ctypes.byref(s_), sums, None), L.radegs_last_error().decode()
+    assert from_sums() == (INVALID, "missing required tensor")                       # radii, means3D, camera
+    s_.radii, s_.means3D, s_.viewmatrix, s_.projmatrix, s_.cam_pos = fake, fake, fake, fake, fake
+    rc, msg = from_sums()
+    assert rc == INVALID and "exactly one of either scale/rotation pair or precomputed 3D covariance" in msg
+    s_.scales, s_.rotations = fake, fake
+    rc, msg = from_sums(fake + 4)
+    assert rc == INVALID and "16-byte aligned" in msg
+    assert L.radegs_backward_from_sums(ctypes.byref(s_), None, None) == INVALID
+    # the switches are read once; a host may have them read again, and ask which formulation its last forward used (none yet: -1)
+    L.radegs_reload_env.restype = None
+    L.radegs_reload_env()
+    L.radegs_last_forward_used_streams.restype = ctypes.c_int
+    assert L.radegs_last_forward_used_streams() == -1
+    assert re.search(r"#define\s+RADEGS_ERR_STATE\s+\(-5\)", open(os.path.join(ROOT, "include", "radegs.h")).read())
 
 
 def test_state_sizes_are_host_arithmetic():
