@@ -142,7 +142,7 @@ def main():
         if args.exchange == "factored":
             bucket = FactoredGradExchange(P, s.shs.shape[1], s.sh_degree, dev, timing=True)
         else:
-            bucket = GradBucket(P, s.shs.shape[1], dev)
+            bucket = GradBucket(P, s.shs.shape[1], dev, timing=True)
         C.set_grad_allocator(dev, bucket.allocator)
     counter = [0]
     last_state = []

@@ -79,8 +79,10 @@ class GradBucket:
 
     LAYOUT = ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations")
 
-    def __init__(self, P: int, M: int, device, group=None):
+    def __init__(self, P: int, M: int, device, group=None, timing: bool = False):
         assert_same_on_all_ranks("(P, M)", (P, M), group)
+        self.timing = bool(timing) and torch.device(device).type == "cuda"
+        self._timings = []
         shapes = {"dL_dmeans3D": (P, 3), "dL_dsh": (P, M, 3), "dL_dopacity": (P, 1), "dL_dscales": (P, 3), "dL_drotations": (P, 4)}
         sizes = [int(torch.Size(shapes[k]).numel()) for k in self.LAYOUT]
         self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
@@ -95,10 +97,25 @@ class GradBucket:
 
     def allreduce(self, average: bool = True, group=None):
         if dist.is_available() and dist.is_initialized():
+            t0 = None
+            if self.timing:
+                t0 = torch.cuda.Event(enable_timing=True)
+                t0.record()
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             if average and dist.get_world_size(group) > 1:
                 self.flat /= dist.get_world_size(group)
+            if t0 is not None:
+                t1 = torch.cuda.Event(enable_timing=True)
+                t1.record()
+                self._timings.append((t0, t1))
         return self.views
+
+    def collect_timing(self):
+        """[(exchange_ms, exposed_ms)] since the last collect (after a device synchronisation): the one all-reduce is issued after the
+        backward, so nothing of it is hidden -- both numbers are its duration on the launch stream."""
+        out = [(a.elapsed_time(b),) * 2 for a, b in self._timings]
+        self._timings = []
+        return out
 
 
 class FactoredGradExchange:

@@ -58,6 +58,8 @@ def test_bench_under_the_launcher_with_the_exchange_forced(exchange):
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["value"] > 0 and d["roofline"]["frac"] > 0
+    # what the exchange costs and how much of it the step waits for is on the line whenever an exchange runs (the driver's scaling runs)
+    assert d["exchange_ms"] > 0 and 0 < d["exchange_exposed_ms"] <= d["exchange_ms"] + 1e-3, (d.get("exchange_ms"), d.get("exchange_exposed_ms"))
 
 
 def test_two_ranks_share_one_gpu_through_gloo(tmp_path):
