@@ -333,17 +333,25 @@ def main():
 def other_configs_and_train_iter():
     """Outside the timed region, after it: the other BASELINE configs that run on one GPU, each as a child `bench.py --config Cx`
     (10 steps), reduced to {ms_per_step, value, roofline kernel and fraction}; and scripts/gpu_train_iter.py's full training iteration
-    (3D filter -> rasterizer -> L1/SSIM + normal loss -> backward -> Adam at C2 scale).  A leg that fails or takes more than 150 s
-    reports its error instead of a number -- the headline line is printed either way."""
+    (3D filter -> rasterizer -> L1/SSIM + normal loss -> backward -> Adam at C2 scale).  A leg that fails or runs out of time reports
+    that instead of a number -- the headline line is printed either way, and all legs together get at most 240 s (a leg 120 s)."""
     import re
     import subprocess
     res = {}
+    t_start = time.time()
+    BUDGET, LEG = 240.0, 120.0
+
+    def left():
+        return BUDGET - (time.time() - t_start)
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-other-configs"]
-    legs = [("C3", ["--config", "C3"]), ("C4", ["--config", "C4"]), ("C5", ["--config", "C5"]), ("C2_both_maps", ["--flags", "both"]),
+    legs = [("C4", ["--config", "C4"]), ("C5", ["--config", "C5"]), ("C3", ["--config", "C3"]), ("C2_both_maps", ["--flags", "both"]),
             ("C2_both_maps_forward_only", ["--flags", "both", "--mode", "forward"])]
     for name, extra in legs:
+        if left() < 20.0:
+            res[name] = {"error": "skipped: the 240 s the legs share were used up"}
+            continue
         try:
-            p = subprocess.run(base + extra, capture_output=True, text=True, timeout=150)
+            p = subprocess.run(base + extra, capture_output=True, text=True, timeout=min(LEG, left()))
             d = json.loads(p.stdout.strip().splitlines()[-1])
             res[name] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "roofline_kernel": d["roofline"]["kernel"],
                          "roofline_frac": d["roofline"]["frac"], "blend": d["pairs"]["formulation"], "num_rendered": d["config"]["num_rendered"]}
@@ -351,11 +359,14 @@ def other_configs_and_train_iter():
             res[name] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
     train = None
     try:
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_train_iter.py")], capture_output=True, text=True, timeout=150)
+        if left() < 20.0:
+            raise TimeoutError("skipped")
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_train_iter.py")], capture_output=True, text=True, timeout=min(LEG, left()))
         m = re.search(r"full training iteration.*?:\s*([0-9.]+) ms", p.stdout)
         train = float(m.group(1)) if m else None
     except Exception:   # noqa: BLE001
         train = None
+    res["_seconds"] = round(time.time() - t_start, 1)
     return res, train
 
 
