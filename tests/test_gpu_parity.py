@@ -282,6 +282,48 @@ def test_tile_wide_backward_after_stream_forward(monkeypatch):
     check_backward(s, o, seed=64)
 
 
+def test_stream_backward_on_an_overwritten_image_state_reports_an_error_instead_of_trapping(monkeypatch):
+    """The library remembers by address which image buffers hold entry streams; the buffer's own tag is the device-side double check.
+    A caller that overwrites the state between forward and backward (here: zeroes it) gets no kernel trap -- the stream backward
+    finds the wrong tag, touches nothing and raises a flag in the host's mapped words; the NEXT call into the library returns
+    RADEGS_ERR_STATE, and the device context keeps working (a trap kills the process's HIP context)."""
+    import diff_gaussian_rasterization._C as C
+    from synth_scene import to_device
+    monkeypatch.setenv("RADEGS_STREAMS", "1")
+    C.reload_env()
+    dev = torch.device(_dev())
+    s_cpu = make_scene(4000, 176, 120, sh_degree=1, mu_px=2.0, seed=97, kernel_size=0.0, require_coord=False, require_depth=True)
+    s = to_device(s_cpu, dev)
+    g = {k: v.to(dev) for k, v in upstream_grads(s_cpu, 97).items()}
+    e = torch.Tensor([])
+
+    def forward():
+        return C.rasterize_gaussians(s.bg, s.means3D, e, s.opacities, s.scales, s.rotations, 1.0, e, s.viewmatrix, s.projmatrix, s.tanfovx,
+                                     s.tanfovy, s.kernel_size, s.H, s.W, s.shs, s.sh_degree, s.campos, False, s.require_coord, s.require_depth, False)
+
+    def backward(fw):
+        R, color, coord, mcoord, alpha, normal, depth, mdepth, radii, geom, binning, img = fw
+        return C.rasterize_gaussians_backward(s.bg, s.means3D, radii, e, s.scales, s.rotations, 1.0, e, s.viewmatrix, s.projmatrix, s.tanfovx,
+                                              s.tanfovy, s.kernel_size, g["color"], g["coord"], g["mcoord"], g["depth"], g["mdepth"], g["alpha"],
+                                              g["normal"], normal, s.shs, s.sh_degree, s.campos, geom, R, binning, img, alpha, s.require_coord,
+                                              s.require_depth, False)
+    fw = forward()
+    assert C.last_forward_used_streams() is True
+    good = [t.clone() for t in backward(fw) if t is not None]
+    fw = forward()
+    fw[11].zero_()                       # the image state, tag included, is gone
+    backward(fw)                         # queues the stream backward on it: no trap, no exception yet
+    torch.cuda.synchronize(dev)
+    with pytest.raises(RuntimeError, match="does not hold the entry streams"):
+        forward()                        # the next call into the library on this thread reports it ...
+    fw = forward()                       # ... once; the context is alive and the following calls are right again
+    again = [t for t in backward(fw) if t is not None]
+    torch.cuda.synchronize(dev)
+    for a, b in zip(again, good):
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 1e-3 * scale
+
+
 def test_forward_is_deterministic_and_backward_stable():
     from gpu_util import HipRun
     s = make_scene(20000, 320, 240, sh_degree=3, mu_px=2.0, seed=8, require_coord=False, require_depth=True)
