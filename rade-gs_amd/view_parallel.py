@@ -6,7 +6,6 @@ BASELINE.json's north_star asks for.  The six gradient tensors (xyz, SH, opacity
 = 59 floats = 236 B per Gaussian) are packed into ONE flat bucket so a single RCCL all-reduce moves
 them over xGMI; with `backend="gloo"` the same code runs on CPU tensors (tests/test_dist_gloo.py).
 """
-import os
 from typing import Dict, Iterable, List
 
 import torch
@@ -144,7 +143,7 @@ class FactoredGradExchange:
 
     SMALL = ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations")
 
-    def __init__(self, P: int, M: int, degree: int, device, group=None, grad_chunks: int = 2, timing: bool = False):
+    def __init__(self, P: int, M: int, degree: int, device, group=None, grad_chunks: int = 2, timing: bool = False, early: bool = True):
         from diff_gaussian_rasterization import _C
         self._C, self.P, self.M, self.D, self.group = _C, P, M, degree, group
         assert_same_on_all_ranks("(P, M, sh_degree, grad_chunks)", (P, M, degree, grad_chunks), group)
@@ -171,6 +170,7 @@ class FactoredGradExchange:
         self._rows_done = 0       # rows of the small tensors whose all-reduce has been issued
         self._campos = None
         self.grad_chunks = int(grad_chunks)
+        self.early = bool(early)     # False: issue every collective from exchange() (no overlap with the backward)
         self.timing = bool(timing) and self.device.type == "cuda"
         self._t_first = None      # event on the side stream before the step's first collective (timing)
         self._timings = []        # (first collective issued, exchange() entered, exchange() done) event triples, one per step
@@ -181,7 +181,7 @@ class FactoredGradExchange:
 
     @property
     def _early_ok(self):
-        if os.environ.get("RADEGS_EARLY_ALLGATHER", "1") == "0":     # escape hatch: issue every collective from exchange()
+        if not self.early:
             return False
         return self._campos is not None and dist.is_available() and dist.is_initialized()
 
