@@ -94,6 +94,9 @@ int radegs_forward(const RadegsFwdArgs* args, radegs_alloc_fn geom_alloc, void* 
                    void* binning_user, radegs_alloc_fn image_alloc, void* image_user, void* stream);
 
 typedef struct RadegsBwdArgs {
+  size_t struct_size;           /* sizeof(RadegsBwdArgs) of the header the CALLER was compiled against.  The structure has grown at its
+                                   tail between releases; radegs_backward / radegs_backward_from_sums refuse a size they do not know
+                                   (RADEGS_ERR_INVALID_ARG) instead of reading hooks past the end of a shorter structure */
   int P, D, M, R;               /* R = num_rendered returned by the forward */
   int width, height;
   const float* background;
@@ -155,6 +158,10 @@ typedef struct RadegsBwdArgs {
   int grad_chunks;
   void (*grads_ready)(void* user, int first, int count);
   void* grads_ready_user;
+  /* Inspection (tests): 1 = after the call the accumulation scratch holds every visible Gaussian's sums in the order and units of
+   * radegs_backward_from_sums' `sums`, except the constant factors listed there (1/focal on the plane sums, W/2 and H/2 on mean2D).
+   * Without it the record's mean2D / conic slots may hold the blend backward's private intermediate (raw moments, csrc/rg_streams.inc). */
+  int keep_sums;
 } RadegsBwdArgs;
 
 /* `accum_alloc` provides the per-Gaussian accumulation scratch (64 or 128 B per Gaussian). */

@@ -924,6 +924,7 @@ struct BlendBwdArgs {
   const float* dL_dpix; const float* dL_dcoord; const float* dL_dmcoord; const float* dL_ddepth; const float* dL_dmdepth;
   const float* dL_dalpha; const float* dL_dnormal;
   float* acc;  // [P][REC] per-Gaussian sums, SplatAcc order
+  int P;       // Gaussians (rows of acc)
   const uint32_t* stream_tag;   // ImageState::stream_tag (stream kernels only)
   uint32_t* stream_err;         // mapped host word: set when stream_tag says this buffer holds no entry streams (may be nullptr)
   const uint32_t* blk_base; const uint32_t* blk_consumed; const uint32_t* blk_chunks; const uint32_t* blk_order;   // sub-tile entry streams (rg_streams.inc)
@@ -1253,6 +1254,11 @@ struct PreBwdArgs {
   int opacity_grad_intended;  // RadegsBwdArgs::opacity_grad_intended (include/radegs.h)
   int drgb_done;              // dL_drgb_clamped was already written by drgb_clamped_kernel (RadegsBwdArgs::drgb_ready)
   int acc_final;              // the records hold the reference's FINAL per-Gaussian sums (constant factors applied): radegs_backward_from_sums
+  int acc_raw;                // components 9..14 of the records are raw moments of u = G dL/dalpha (blend_bwd_streams_kernel, rg_streams.inc):
+                              // the mean2D / conic sums are formed here, once per Gaussian; 2: and the record is written back in the
+                              // reference's form (debugging / tests: RadegsBwdArgs::keep_sums)
+  const float4* splat_b;      // coord-map modes: camera planes, for the mean2D sums of a raw record
+  float* acc_out;             // acc_raw == 2: where the converted record goes (the accumulator itself)
   int vec_slab;               // the SH slab moves in 16-byte pieces (3M % 4 == 0, 3M <= 48, shs and dL_dsh 16-byte aligned)
   int first_block;            // this launch covers the Gaussians from first_block * 128 on (RadegsBwdArgs::grad_chunks)
 };
@@ -1387,6 +1393,26 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
         acc.dvp[0] = acc.dvp[1] = acc.dvp[2] = 0.f;
 #pragma unroll
         for (int c = 0; c < 6; c++) acc.dcp[c] = 0.f;
+      }
+      if (a.acc_raw) {   // raw moments -> the reference's sums (backward.cu:981-1012; layout: rg_streams.inc)
+        const float4 sa0 = a.splat_a[4 * i], sa1 = a.splat_a[4 * i + 1], sa2 = a.splat_a[4 * i + 2], sa3 = a.splat_a[4 * i + 3];
+        const float cx = sa0.z, cy = sa0.w, cz = sa1.x, op = sa1.y, rpx = sa2.w, rpy = sa3.x;
+        const float sux = acc.dmean2D[0], suy = acc.dmean2D[1];
+        float mx2 = fmaf(rpx, acc.dts, -op * fmaf(cx, sux, cy * suy));
+        float my2 = fmaf(rpy, acc.dts, -op * fmaf(cy, sux, cz * suy));
+        if (a.rec == 32) {
+          const float4 sb0 = a.splat_b[3 * i], sb1 = a.splat_b[3 * i + 1];
+          mx2 = fmaf(acc.dvp[0], sb0.x, fmaf(acc.dvp[1], sb0.z, fmaf(acc.dvp[2], sb1.x, mx2)));
+          my2 = fmaf(acc.dvp[0], sb0.y, fmaf(acc.dvp[1], sb0.w, fmaf(acc.dvp[2], sb1.y, my2)));
+        }
+        acc.dmean2D[0] = mx2; acc.dmean2D[1] = my2; acc.dmean2D[2] *= fabsf(op);
+        const float hop = -0.5f * op;
+        acc.dconic[0] *= hop; acc.dconic[1] *= hop; acc.dconic[2] *= hop;
+        if (a.acc_raw == 2) {
+          float4* w = reinterpret_cast<float4*>(a.acc_out + i * a.rec);
+          w[2] = make_float4(r2.x, acc.dmean2D[0], acc.dmean2D[1], acc.dmean2D[2]);
+          w[3] = make_float4(acc.dconic[0], acc.dconic[1], acc.dconic[2], acc.dop);
+        }
       }
       // constant factors the blend backward left out of its sums (linear, so they commute with the sum):
       // 1/focal on the plane gradients (backward.cu:917-922,939-940), W/2 and H/2 on mean2D (:1002-1003)

@@ -41,7 +41,7 @@ class RadegsFwdArgs(ctypes.Structure):
 
 
 class RadegsBwdArgs(ctypes.Structure):
-    _fields_ = [("P", ctypes.c_int), ("D", ctypes.c_int), ("M", ctypes.c_int), ("R", ctypes.c_int), ("width", ctypes.c_int),
+    _fields_ = [("struct_size", ctypes.c_size_t), ("P", ctypes.c_int), ("D", ctypes.c_int), ("M", ctypes.c_int), ("R", ctypes.c_int), ("width", ctypes.c_int),
                 ("height", ctypes.c_int),
                 ("background", ctypes.c_void_p), ("means3D", ctypes.c_void_p), ("shs", ctypes.c_void_p),
                 ("colors_precomp", ctypes.c_void_p), ("alphas", ctypes.c_void_p), ("scales", ctypes.c_void_p),
@@ -60,7 +60,8 @@ class RadegsBwdArgs(ctypes.Structure):
                 ("require_coord", ctypes.c_int), ("require_depth", ctypes.c_int), ("debug", ctypes.c_int),
                 ("dL_drgb_clamped", ctypes.c_void_p), ("opacity_grad_intended", ctypes.c_int),
                 ("drgb_ready", ctypes.c_void_p), ("drgb_ready_user", ctypes.c_void_p),
-                ("grad_chunks", ctypes.c_int), ("grads_ready", ctypes.c_void_p), ("grads_ready_user", ctypes.c_void_p)]
+                ("grad_chunks", ctypes.c_int), ("grads_ready", ctypes.c_void_p), ("grads_ready_user", ctypes.c_void_p),
+                ("keep_sums", ctypes.c_int)]
 
 
 class RadegsIntegrateArgs(ctypes.Structure):
@@ -414,7 +415,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 except Exception as ex:  # noqa: BLE001 -- must not unwind through the C frame
                     ready_err.append(ex)
             chunks_cb = _GRADS_READY_FN(_chunk)
-        a = RadegsBwdArgs(P, int(degree), M, int(R), W, H, _ptr(bg), _ptr(m3), _ptr(shs), _ptr(col), _ptr(al), _ptr(sc), _ptr(rot),
+        a = RadegsBwdArgs(ctypes.sizeof(RadegsBwdArgs), P, int(degree), M, int(R), W, H, _ptr(bg), _ptr(m3), _ptr(shs), _ptr(col), _ptr(al), _ptr(sc), _ptr(rot),
                           _ptr(cov), _ptr(vm), _ptr(pm), _ptr(cp), float(scale_modifier), float(tan_fovx), float(tan_fovy),
                           float(kernel_size), _ptr(rad), _ptr(nm), _ptr(gb) if gb.numel() else None, _ptr(bb) if bb.numel() else None,
                           _ptr(ib) if ib.numel() else None, _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(g[4]), _ptr(g[5]),
@@ -422,7 +423,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                           _ptr(dL_dsh) if (M and dL_dsh is not None) else None, _ptr(dL_dscales), _ptr(dL_drotations),
                           int(bool(require_coord)), int(bool(require_depth)), int(bool(debug)), _ptr(drgb), int(bool(OPACITY_GRAD_INTENDED)),
                           ctypes.cast(ready_cb, ctypes.c_void_p) if ready_cb is not None else None, None,
-                          nchunks, ctypes.cast(chunks_cb, ctypes.c_void_p) if chunks_cb is not None else None, None)
+                          nchunks, ctypes.cast(chunks_cb, ctypes.c_void_p) if chunks_cb is not None else None, None,
+                          int(bool(KEEP_ACC)))
         with torch.cuda.device(dev):
             rc = L.radegs_backward(ctypes.byref(a), acc.cb, None, _stream(dev))
         acc.release()
@@ -461,12 +463,12 @@ def backward_from_sums(sums, means3D, radii, colors, scales, rotations, scale_mo
     sc, rot, cov = _f32(scales, "scales"), _f32(rotations, "rotations"), _f32(cov3D_precomp, "cov3D_precomp")
     vm, pm, cp, shs = _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix"), _f32(campos, "campos"), _f32(sh, "shs")
     rad, gb = radii.contiguous(), geomBuffer.contiguous()
-    a = RadegsBwdArgs(P, int(degree), M, 0, int(image_width), int(image_height), None, _ptr(m3), _ptr(shs), _ptr(col), None, _ptr(sc), _ptr(rot),
+    a = RadegsBwdArgs(ctypes.sizeof(RadegsBwdArgs), P, int(degree), M, 0, int(image_width), int(image_height), None, _ptr(m3), _ptr(shs), _ptr(col), None, _ptr(sc), _ptr(rot),
                       _ptr(cov), _ptr(vm), _ptr(pm), _ptr(cp), float(scale_modifier), float(tan_fovx), float(tan_fovy), float(kernel_size),
                       _ptr(rad), None, _ptr(gb), None, None, None, None, None, None, None, None, None,
                       _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
                       _ptr(dL_dsh) if M else None, _ptr(dL_dscales), _ptr(dL_drotations), int(bool(require_coord)), 0, 0, None,
-                      int(bool(OPACITY_GRAD_INTENDED)), None, None, 0, None, None)
+                      int(bool(OPACITY_GRAD_INTENDED)), None, None, 0, None, None, 0)
     with torch.cuda.device(dev):
         rc = L.radegs_backward_from_sums(ctypes.byref(a), _ptr(sm), _stream(dev))
     _check(rc, "radegs_backward_from_sums")

@@ -37,7 +37,7 @@ class DevelopWithHip(develop):
 
 setup(
     name="rade-gs-amd",
-    version="0.5.0",
+    version="0.6.0",
     description="MI355X-native differentiable Gaussian-splat rasterizer behind RaDe-GS's diff_gaussian_rasterization API (HIP, gfx950)",
     packages=["diff_gaussian_rasterization", "simple_knn"],
     py_modules=["graphics_utils", "loss_utils", "gaussian_model_ops", "fused_adam", "view_parallel", "synth_scene"],

@@ -140,6 +140,11 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_device():
     # the backward: state buffers and gradient outputs are checked before anything runs
     b = C.RadegsBwdArgs()
     b.P = 3
+    # a caller compiled against a different header (a structure of another size) is refused before any field beyond it is read
+    assert L.radegs_backward(ctypes.byref(b), cb, None, None) == INVALID and "struct_size" in L.radegs_last_error().decode()
+    b.struct_size = ctypes.sizeof(C.RadegsBwdArgs) - 8
+    assert L.radegs_backward(ctypes.byref(b), cb, None, None) == INVALID and "struct_size" in L.radegs_last_error().decode()
+    b.struct_size = ctypes.sizeof(C.RadegsBwdArgs)
     assert L.radegs_backward(ctypes.byref(b), cb, None, None) == INVALID and "state buffers missing" in L.radegs_last_error().decode()
     b.geom_buffer, b.image_buffer = fake, fake
     assert L.radegs_backward(ctypes.byref(b), cb, None, None) == INVALID and "gradient outputs missing" in L.radegs_last_error().decode()
@@ -150,6 +155,8 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_device():
     L.radegs_backward_from_sums.restype = ctypes.c_int
     L.radegs_backward_from_sums.argtypes = [ctypes.POINTER(C.RadegsBwdArgs), ctypes.c_void_p, ctypes.c_void_p]
     s_ = C.RadegsBwdArgs()
+    assert L.radegs_backward_from_sums(ctypes.byref(s_), fake, None) == INVALID and "struct_size" in L.radegs_last_error().decode()
+    s_.struct_size = ctypes.sizeof(C.RadegsBwdArgs)
     s_.P, s_.D, s_.M, s_.width, s_.height = 3, 0, 1, 32, 32
     s_.geom_buffer = fake
     for f in ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dscale", "dL_drot"):
