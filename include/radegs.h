@@ -162,6 +162,12 @@ typedef struct RadegsBwdArgs {
    * radegs_backward_from_sums' `sums`, except the constant factors listed there (1/focal on the plane sums, W/2 and H/2 on mean2D).
    * Without it the record's mean2D / conic slots may hold the blend backward's private intermediate (raw moments, csrc/rg_streams.inc). */
   int keep_sums;
+  /* 1 = the caller promises that the buffer `accum_alloc` is about to hand out is ALL ZEROS, and wants it back all zeros: the call then
+   * skips its fill of the scratch (64 | 128 B per Gaussian: 10 us at 1M Gaussians) and the per-Gaussian kernel clears every record it
+   * consumes.  Meant for a caller that keeps ONE scratch buffer per (device, stream) across calls: zero it once, pass 1 from then on,
+   * and fall back to 0 after any call that returned an error or ran with keep_sums (the buffer is then in an unknown state).
+   * 0: the scratch may hold anything; it is filled with zeros first and left as the kernels leave it. */
+  int acc_reuse;
 } RadegsBwdArgs;
 
 /* `accum_alloc` provides the per-Gaussian accumulation scratch (64 or 128 B per Gaussian). */

@@ -28,6 +28,7 @@
 //     share splat records -> per-XCD L2 reuse).
 // No MFMA: there is no dense contraction on this path.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "rg_blend.h"
 #include "rg_layout.h"
@@ -1259,6 +1260,7 @@ struct PreBwdArgs {
                               // reference's form (debugging / tests: RadegsBwdArgs::keep_sums)
   const float4* splat_b;      // coord-map modes: camera planes, for the mean2D sums of a raw record
   float* acc_out;             // acc_raw == 2: where the converted record goes (the accumulator itself)
+  int acc_rezero;             // clear every consumed record (RadegsBwdArgs::acc_reuse): the accumulator goes back to its owner all zeros
   int vec_slab;               // the SH slab moves in 16-byte pieces (3M % 4 == 0, 3M <= 48, shs and dL_dsh 16-byte aligned)
   int first_block;            // this launch covers the Gaussians from first_block * 128 on (RadegsBwdArgs::grad_chunks)
 };
@@ -1338,12 +1340,23 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
   int radius = 0;
   unsigned cflags = 0;
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0, rq = r0;
+  float4 sa0 = r0, sa1 = r0, sa2 = r0, sa3 = r0, sb0 = r0, sb1 = r0;
   float r6 = 0.f, m0 = 0.f, m1 = 0.f, m2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
   if (live) {
     radius = a.radii[idx];
     const float4* r = reinterpret_cast<const float4*>(a.acc + i * a.rec);
     r0 = r[0]; r1 = r[1]; r2 = r[2]; r3 = r[3];
     if (a.rec == 32) { r4 = r[4]; r5 = r[5]; r6 = r[6].x; }
+    if (a.acc_raw) {   // the Gaussian's blend record (conic, opacity, depth plane) for the raw moments' coefficients: requested with the rest
+      sa0 = a.splat_a[4 * i]; sa1 = a.splat_a[4 * i + 1]; sa2 = a.splat_a[4 * i + 2]; sa3 = a.splat_a[4 * i + 3];
+      if (a.rec == 32) { sb0 = a.splat_b[3 * i]; sb1 = a.splat_b[3 * i + 1]; }
+    }
+    if (a.acc_rezero && radius > 0) {   // only a visible Gaussian's record can have been touched (it is in no list otherwise)
+      float4* w = reinterpret_cast<float4*>(a.acc_out + i * a.rec);
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      w[0] = z; w[1] = z; w[2] = z; w[3] = z;
+      if (a.rec == 32) { w[4] = z; w[5] = z; w[6] = z; }
+    }
     m0 = a.means3D[3 * i]; m1 = a.means3D[3 * i + 1]; m2 = a.means3D[3 * i + 2];
     if (has_sr) {
       s0 = a.scales[3 * i]; s1 = a.scales[3 * i + 1]; s2 = a.scales[3 * i + 2];
@@ -1395,13 +1408,11 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
         for (int c = 0; c < 6; c++) acc.dcp[c] = 0.f;
       }
       if (a.acc_raw) {   // raw moments -> the reference's sums (backward.cu:981-1012; layout: rg_streams.inc)
-        const float4 sa0 = a.splat_a[4 * i], sa1 = a.splat_a[4 * i + 1], sa2 = a.splat_a[4 * i + 2], sa3 = a.splat_a[4 * i + 3];
         const float cx = sa0.z, cy = sa0.w, cz = sa1.x, op = sa1.y, rpx = sa2.w, rpy = sa3.x;
         const float sux = acc.dmean2D[0], suy = acc.dmean2D[1];
         float mx2 = fmaf(rpx, acc.dts, -op * fmaf(cx, sux, cy * suy));
         float my2 = fmaf(rpy, acc.dts, -op * fmaf(cy, sux, cz * suy));
         if (a.rec == 32) {
-          const float4 sb0 = a.splat_b[3 * i], sb1 = a.splat_b[3 * i + 1];
           mx2 = fmaf(acc.dvp[0], sb0.x, fmaf(acc.dvp[1], sb0.z, fmaf(acc.dvp[2], sb1.x, mx2)));
           my2 = fmaf(acc.dvp[0], sb0.y, fmaf(acc.dvp[1], sb0.w, fmaf(acc.dvp[2], sb1.y, my2)));
         }
@@ -1433,7 +1444,7 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
       }
       // what the reference's computeCov2DCUDA reads as `conic_opacity[idx].w` is dL_dconic[idx].w (argument slip at
       // rasterizer_impl.cu:568); the stored opacity*coef only with opacity_grad_intended (include/radegs.h)
-      const float op_combined = a.opacity_grad_intended ? a.splat_a[4 * i + 1].y : acc.dconic[2];
+      const float op_combined = a.opacity_grad_intended ? (a.acc_raw ? sa1.y : a.splat_a[4 * i + 1].y) : acc.dconic[2];
       if (row) {  // rows beyond the active degree stay zero
         const int K = (a.D + 1) * (a.D + 1);
         for (int c = K * 3; c < rowf; c++) row[c] = 0;

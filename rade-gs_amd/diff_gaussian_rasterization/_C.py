@@ -61,7 +61,7 @@ class RadegsBwdArgs(ctypes.Structure):
                 ("dL_drgb_clamped", ctypes.c_void_p), ("opacity_grad_intended", ctypes.c_int),
                 ("drgb_ready", ctypes.c_void_p), ("drgb_ready_user", ctypes.c_void_p),
                 ("grad_chunks", ctypes.c_int), ("grads_ready", ctypes.c_void_p), ("grads_ready_user", ctypes.c_void_p),
-                ("keep_sums", ctypes.c_int)]
+                ("keep_sums", ctypes.c_int), ("acc_reuse", ctypes.c_int)]
 
 
 class RadegsIntegrateArgs(ctypes.Structure):
@@ -234,6 +234,9 @@ def _forget_image(holder):
 # buffers -- is first overwritten with 0xFF bytes / NaN, so a kernel that reads something this call has not written, or leaves a
 # pixel unwritten, shows up in the results instead of hiding behind whatever the allocator's recycled memory happened to hold.
 _POISON = os.environ.get("RADEGS_DEBUG_POISON", "0") == "1"
+# RADEGS_ACC_REUSE=0: a fresh accumulation scratch per backward, filled with zeros by the call (the behaviour before round 6); default:
+# one scratch per (device, stream), handed back zeroed by the backward itself (RadegsBwdArgs.acc_reuse)
+ACC_REUSE = os.environ.get("RADEGS_ACC_REUSE", "1") != "0"
 
 
 class _Resizable:
@@ -269,6 +272,39 @@ class _Resizable:
         """Drop the ctypes callback once the native call has returned: it closes over `self`, and the cycle would keep the
         tensor (hundreds of MB of device memory at 1M+ Gaussians) alive until Python's cyclic GC happens to run."""
         self.cb = None
+
+
+class _Fixed:
+    """allocator callback over a tensor that already exists (the cached accumulation scratch)"""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+        self.error = None
+
+        def _cb(_user, nbytes):
+            if int(nbytes) > self.tensor.numel():
+                self.error = RuntimeError(f"accumulation scratch of {self.tensor.numel()} B asked for {int(nbytes)} B")
+                return 0
+            return self.tensor.data_ptr()
+
+        self.cb = _ALLOC_FN(_cb)
+
+    def release(self):
+        self.cb = None
+
+
+_ACC_SCRATCH = {}   # (device index, stream handle) -> all-zero uint8 tensor, kept zero by the backward itself (RadegsBwdArgs.acc_reuse)
+
+
+def _acc_scratch(key, nbytes, device):
+    """The zeroed accumulation scratch of this (device, stream), grown (and zeroed again) when a call needs more; at most 8 are kept."""
+    t = _ACC_SCRATCH.get(key)
+    if t is None or t.numel() < nbytes:
+        if len(_ACC_SCRATCH) >= 8:
+            _ACC_SCRATCH.clear()
+        t = torch.zeros(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+        _ACC_SCRATCH[key] = t
+    return t
 
 
 def _zero_maps(channels, H, W, device):
@@ -392,7 +428,12 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         gb, bb, ib = geomBuffer.contiguous(), binningBuffer.contiguous(), imageBuffer.contiguous()
         if not sc is None and rot is None:
             raise RuntimeError("scales given without rotations")
-        acc = _Resizable(dev)
+        # the accumulation scratch: ONE buffer per (device, stream), zeroed once and handed back zeroed by every successful call
+        # (RadegsBwdArgs.acc_reuse) -- unless its contents are wanted afterwards (KEEP_ACC), which takes a scratch of its own
+        abytes = P * (128 if require_coord else 64)
+        akey = (dev.index if dev.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream(dev).cuda_stream))
+        acc_cached = None if (KEEP_ACC or _POISON or not ACC_REUSE) else _acc_scratch(akey, abytes, dev)
+        acc = _Resizable(dev) if acc_cached is None else _Fixed(acc_cached)
         ready_cb, ready_err = None, []
         owner = getattr(grad_alloc, "__self__", None)
         if drgb is not None and owner is not None and callable(getattr(owner, "drgb_ready", None)) and getattr(owner, "early_drgb", False):
@@ -424,10 +465,12 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                           int(bool(require_coord)), int(bool(require_depth)), int(bool(debug)), _ptr(drgb), int(bool(OPACITY_GRAD_INTENDED)),
                           ctypes.cast(ready_cb, ctypes.c_void_p) if ready_cb is not None else None, None,
                           nchunks, ctypes.cast(chunks_cb, ctypes.c_void_p) if chunks_cb is not None else None, None,
-                          int(bool(KEEP_ACC)))
+                          int(bool(KEEP_ACC)), int(acc_cached is not None))
         with torch.cuda.device(dev):
             rc = L.radegs_backward(ctypes.byref(a), acc.cb, None, _stream(dev))
         acc.release()
+        if acc_cached is not None and (rc != 0 or acc.error is not None or ready_err):
+            _ACC_SCRATCH.pop(akey, None)   # the scratch is in an unknown state: the next call starts from a fresh one
         if acc.error is not None:
             raise acc.error
         if ready_err:
@@ -468,7 +511,7 @@ def backward_from_sums(sums, means3D, radii, colors, scales, rotations, scale_mo
                       _ptr(rad), None, _ptr(gb), None, None, None, None, None, None, None, None, None,
                       _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
                       _ptr(dL_dsh) if M else None, _ptr(dL_dscales), _ptr(dL_drotations), int(bool(require_coord)), 0, 0, None,
-                      int(bool(OPACITY_GRAD_INTENDED)), None, None, 0, None, None, 0)
+                      int(bool(OPACITY_GRAD_INTENDED)), None, None, 0, None, None, 0, 0)
     with torch.cuda.device(dev):
         rc = L.radegs_backward_from_sums(ctypes.byref(a), _ptr(sm), _stream(dev))
     _check(rc, "radegs_backward_from_sums")

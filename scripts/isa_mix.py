@@ -122,7 +122,8 @@ def hottest_loop(ins, asm):
     def score(s):
         ops = [ins[k][1] for k in range(s[0], s[1] + 1)]
         return (any(o.startswith("ds_read") for o in ops), sum(o.startswith("v_") for o in ops))
-    return max(inner, key=score)
+    ranked = sorted(inner, key=score, reverse=True)
+    return ranked
 
 
 def main():
@@ -137,22 +138,30 @@ def main():
     if dump:
         open(dump, "w").write(asm)
     ins = parse(asm)
-    span = (0, len(ins) - 1)
-    if "--loop" in sys.argv:
-        span = hottest_loop(ins, asm)
+    spans = [(0, len(ins) - 1)]
+    if "--loop" in sys.argv:   # every innermost loop that reads LDS and holds at least 40 VALU instructions, largest first
+        ranked = hottest_loop(ins, asm)
+        spans = [sp for sp in ranked if sum(ins[k][1].startswith("v_") for k in range(sp[0], sp[1] + 1)) >= 40
+                 and any(ins[k][1].startswith("ds_read") for k in range(sp[0], sp[1] + 1))] or ranked[:1]
+    for span in spans:
+        report(name, ins, span, "--loop" in sys.argv, "--ops" in sys.argv)
+
+
+def report(name, ins, span, is_loop, show_ops):
     sel = ins[span[0]:span[1] + 1]
     cls = Counter(classify(op, text) for _, op, text in sel)
     ops = Counter(op for _, op, _ in sel)
-    print(f"{name}: {len(sel)} instructions in {'hottest loop' if '--loop' in sys.argv else 'kernel'} (of {len(ins)})")
+    print(f"{name}: {len(sel)} instructions in {'loop at instruction %d' % span[0] if is_loop else 'kernel'} (of {len(ins)})")
     for k, v in sorted(cls.items(), key=lambda kv: -kv[1]):
         print(f"  {k:28s} {v:5d}")
     # issue cycles per wave64 instruction measured on the part (scripts/ubench/valu_rates.hip)
     cyc = {"valu_full": 2.5, "valu_dpp(half)": 4.5, "valu_other(half)": 4.5, "valu_cndmask_e64(half)": 4.5, "valu_quarter": 8.0,
            "valu_packed(2 passes)": 5.0}
     print(f"  VALU issue-cycle estimate: {sum(cyc.get(k, 0.0) * v for k, v in cls.items()):.0f}")
-    print("  -- by opcode --")
-    for k, v in ops.most_common(40):
-        print(f"  {k:28s} {v:5d}")
+    if show_ops:
+        print("  -- by opcode --")
+        for k, v in ops.most_common(40):
+            print(f"  {k:28s} {v:5d}")
 
 
 if __name__ == "__main__":

@@ -65,8 +65,8 @@ BUDGET = [
     (("blend_fwd_streams_kernelILb1ELb1EE",), 4, 32, 8192),     # coord-map modes (forcing 5 / 6 waves spills); 32 B: one
                                                                  # staged record row goes through scratch once per round of 16 entries
     # the stream backward: staged records + 2.3 KB of row-reduction scratch; 6 826 B = 160 KB / 24 is what lets a CU hold 6 waves per SIMD
-    (("blend_bwd_streams_kernelILb0ELb1EE",), 6, 0, 6826),      # the dominant kernel
-    (("blend_bwd_streams_kernelILb0ELb0EE",), 6, 0, 6826),
+    (("blend_bwd_streams_kernelILb0ELb1EE",), 5, 0, 6826),      # the dominant kernel (5 waves: measured faster than 6 with a spill)
+    (("blend_bwd_streams_kernelILb0ELb0EE",), 5, 0, 6826),
     (("blend_bwd_streams_kernelILb1ELb1EE",), 4, 0, 10240),     # coord-map modes: two 64-byte lines per (block, entry), one atomic instruction each
     (("blend_bwd_streams_kernelILb1ELb0EE",), 4, 0, 10240),
     (("preprocess_fwd_kernelILb0E",), 6, 0, 0),
