@@ -974,6 +974,71 @@ __device__ __forceinline__ float wave_reduce_scatter(float (&v)[N], int lane) {
   return r;
 }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// ---- per-(block, entry) reduction of the 16 per-Gaussian sums over the 16 lanes of a DPP row (round 6) ----
+// Rounds 2-5 ran all four butterfly stages on the VALU (24 bank-masked DPP adds + 13 selects / adds = 37 half-rate instructions,
+// ~165 of the loop's ~530 issue cycles).  Now only the first stage does: a DPP add with a bank mask only writes the lanes of the
+// enabled banks (4 lanes each), so "lanes 0..7 keep components 0..7, lanes 8..15 keep 8..15" is two masked adds per component
+// (row_ror:8 pairs lane l with l ^ 8).  The remaining 8 x 8 transposition goes through wave-private LDS: every lane stores its 8
+// partial sums (two ds_write_b128), lane l reads component l & 7 of the 8 lanes of its half row (four ds_read2_b32) and adds them
+// up with 7 full-rate adds: 16 DPP + 7 adds on the VALU (~90 cycles), 6 LDS instructions that other waves' VALU work covers.
+// (All sixteen components through LDS would need 4 KB per wave -- with the staged records 8.7 KB, four waves per SIMD.)
+// Layout of a row's 576-byte scratch (144 floats): lane j's 8 sums at float offset (j >> 3) * 72 + (j & 7) * 8, its two 16-byte
+// halves swapped when bit 2 of j is set; the +32 bytes per half row and +64 per row put the two half rows and the two rows that share
+// an LDS cycle on different banks for the reads, the swap does the same for the eight lanes of a ds_write_b128 group.
+constexpr int kRedRowFloats = 144;
+__device__ __forceinline__ void row_reduce16_first_stage(float (&v)[16]) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %5, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %6, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %7, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "s_nop 1"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+      : "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+}
+struct RowReduceAddr {   // per lane, set up once per kernel
+  float* w0; float* w1;         // where this lane's two 16-byte halves go
+  const float* r0; const float* r1;   // component (lane & 7) of source lanes 0..3 / 4..7 of the half row (+ 8 k floats for source k)
+};
+__device__ __forceinline__ RowReduceAddr row_reduce_addr(float* scratch, int grp, int l) {
+  RowReduceAddr a;
+  float* row = scratch + grp * kRedRowFloats;
+  const int sw = (l >> 2) & 1, c8 = l & 7, half = l >> 3;
+  a.w0 = row + half * 72 + c8 * 8 + sw * 4;
+  a.w1 = row + half * 72 + c8 * 8 + (sw ^ 1) * 4;
+  a.r0 = row + half * 72 + (c8 >> 2) * 4 + (c8 & 3);
+  a.r1 = row + half * 72 + ((c8 >> 2) ^ 1) * 4 + (c8 & 3);
+  return a;
+}
+// In: v[c] = this lane's partial sum of component c.  Returns the row total of component (lane & 15).
+__device__ __forceinline__ float row_reduce16(float (&v)[16], const RowReduceAddr& ad) {
+  row_reduce16_first_stage(v);
+  *reinterpret_cast<v4f*>(ad.w0) = v4f{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<v4f*>(ad.w1) = v4f{v[4], v[5], v[6], v[7]};
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const float t0 = ad.r0[0], t1 = ad.r0[8], t2 = ad.r0[16], t3 = ad.r0[24];
+  const float t4 = ad.r1[32], t5 = ad.r1[40], t6 = ad.r1[48], t7 = ad.r1[56];
+  __builtin_amdgcn_wave_barrier();   // the next call's stores stay behind these loads
+  return ((t0 + t1) + (t2 + t3)) + ((t4 + t5) + (t6 + t7));
+}
+
 // ------------------------------------------------------------------ blend, bwd (packed) ----
 // Second formulation of the same backward: the pixels of one lane are handled in PAIRS as 2-wide
 // fp32 vectors (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do two pixels per issue slot), and a
@@ -996,6 +1061,7 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
   __shared__ float4 lds_a[65 * 4];
   __shared__ float4 lds_b[COORD ? 64 * 3 : 1];
   __shared__ uint32_t lds_id[65];
+  __shared__ __attribute__((aligned(16))) float lds_red[4 * kRedRowFloats];   // row_reduce16's scratch (rg_streams.inc)
 
   const int item = xcd_band_remap(blockIdx.x, gridDim.x);
   const int tile = item / WPT, sub = item - tile * WPT;
@@ -1088,6 +1154,7 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, m));
   const f2 cW = bc2(0.5f * W), cH = bc2(0.5f * H);
+  const RowReduceAddr red = row_reduce_addr(lds_red, lane >> 4, lane & 15);
 
   for (int hi = (int)wave_last; hi > 0; hi -= 64) {
     __syncthreads();
@@ -1135,11 +1202,19 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
       if (!__any(anyc)) continue;
       float4 E0, E1, E2;
       if constexpr (COORD) { E0 = lds_b[j * 3 + 0]; E1 = lds_b[j * 3 + 1]; E2 = lds_b[j * 3 + 2]; }
-      f2 gv[REC];
+      // the lane's sums over its pixel pairs; components 9..14 as RAW MOMENTS of h = opacity G dL/dalpha about the Gaussian's centre, everything
+      // "times dx" applied once to the lane's total (all pixels of a lane share dx): the record blend_bwd_streams_kernel writes
+      // (rg_streams.inc), turned into the reference's sums once per Gaussian by preprocess_bwd_kernel (PreBwdArgs::acc_raw)
+      f2 s_col[3], s_nrm[3], s_dt = bc2(0.f), s_dty = bc2(0.f), s_u = bc2(0.f), s_h = bc2(0.f), s_uy = bc2(0.f), s_uyy = bc2(0.f), s_ab = bc2(0.f);
+      f2 s_co[COORD ? 3 : 1], s_coy[COORD ? 3 : 1];
 #pragma unroll
-      for (int i = 0; i < REC; i++) gv[i] = bc2(0.f);
+      for (int c = 0; c < 3; c++) { s_col[c] = bc2(0.f); s_nrm[c] = bc2(0.f); }
+      if constexpr (COORD) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { s_co[c] = bc2(0.f); s_coy[c] = bc2(0.f); }
+      }
       bool contributed = false;
-      const float dxx = dx * dx;
+      const float dxcx = dx * A.z;
 #pragma unroll
       for (int q = 0; q < NP; q++) {
         if (!__any(cand[2 * q] || cand[2 * q + 1])) continue;  // wave-uniform
@@ -1169,11 +1244,10 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
 #pragma unroll
           for (int c = 0; c < 3; c++) {
             V = fma2(bc2(col[c]), dLc[q][c], V);
-            gv[c] = fma2(dch, dLc[q][c], gv[c]);
+            s_col[c] = fma2(dch, dLc[q][c], s_col[c]);
           }
         }
         const bool med0 = act0 && pos == max_cm1[2 * q], med1 = act1 && pos == max_cm1[2 * q + 1];
-        f2 dco[3], dt_ = bc2(0.f);
         if constexpr (COORD) {
           const float cpx[3] = {E0.x, E0.z, E1.x}, cpy[3] = {E0.y, E0.w, E1.y}, vp[3] = {E1.z, E1.w, E2.x};
 #pragma unroll
@@ -1181,27 +1255,25 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
             const f2 cc = fma2(bc2(cpy[c]), dy[q], bc2(fmaf(cpx[c], dx, vp[c])));
             V = fma2(cc, dLco[q][c], V);
             const f2 msel = f2{med0 ? dLmco[q][c][0] : 0.f, med1 ? dLmco[q][c][1] : 0.f};
-            dco[c] = fma2(dch, dLco[q][c], msel);
-            gv[16 + c] += dco[c];
-            gv[19 + 2 * c] = fma2(dco[c], bc2(dx), gv[19 + 2 * c]);
-            gv[20 + 2 * c] = fma2(dco[c], dy[q], gv[20 + 2 * c]);
+            const f2 dco = fma2(dch, dLco[q][c], msel);
+            s_co[c] += dco;
+            s_coy[c] = fma2(dco, dy[q], s_coy[c]);
           }
         }
         if constexpr (DEPTH) {
           const f2 t = fma2(bc2(Dq.x), dy[q], bc2(fmaf(C.w, dx, B.w)));
           V = fma2(t, dLt[q], V);
           const f2 msel = f2{med0 ? dLmt[q][0] : 0.f, med1 ? dLmt[q][1] : 0.f};
-          dt_ = fma2(dch, dLt[q], msel);
-          gv[3] += dt_;
-          gv[4] = fma2(dt_, bc2(dx), gv[4]);
-          gv[5] = fma2(dt_, dy[q], gv[5]);
+          const f2 dt_ = fma2(dch, dLt[q], msel);
+          s_dt += dt_;
+          s_dty = fma2(dt_, dy[q], s_dty);
         }
         if constexpr (NORMAL) {
           const float nn[3] = {Dq.y, Dq.z, Dq.w};
 #pragma unroll
           for (int c = 0; c < 3; c++) {
             V = fma2(bc2(nn[c]), dLn[q][c], V);
-            gv[6 + c] = fma2(dch, dLn[q][c], gv[6 + c]);
+            s_nrm[c] = fma2(dch, dLn[q][c], s_nrm[c]);
           }
         }
         f2 dL_dopa = V - Q[q];
@@ -1210,35 +1282,41 @@ __global__ void __launch_bounds__(64, (COORD ? (PPL == 4 ? 1 : 2) : (PPL == 4 ? 
         dL_dopa = fma2(inv1ma, tb[q], dL_dopa);
 
         const f2 u = G * dL_dopa;
-        const f2 h = bc2(B.y) * u;
-        const f2 ex = fma2(dy[q], bc2(A.w), bc2(dx * A.z));
-        const f2 ey = fma2(dy[q], bc2(B.x), bc2(dx * A.w));
-        const f2 gx_ = -h * ex, gy_ = -h * ey;
-        f2 dL_ddelx = gx_, dL_ddely = gy_;
-        if constexpr (COORD) {
-          dL_ddelx = fma2(dco[0], bc2(E0.x), fma2(dco[1], bc2(E0.z), fma2(dco[2], bc2(E1.x), dL_ddelx)));
-          dL_ddely = fma2(dco[0], bc2(E0.y), fma2(dco[1], bc2(E0.w), fma2(dco[2], bc2(E1.y), dL_ddely)));
-        }
-        if constexpr (DEPTH) {
-          dL_ddelx = fma2(dt_, bc2(C.w), dL_ddelx);
-          dL_ddely = fma2(dt_, bc2(Dq.x), dL_ddely);
-        }
-        gv[9] += dL_ddelx;
-        gv[10] += dL_ddely;
-        gv[11] = fma2(__builtin_elementwise_abs(gy_), cH, fma2(__builtin_elementwise_abs(gx_), cW, gv[11]));
-        const f2 hh = bc2(-0.5f) * h;
-        gv[12] = fma2(hh, bc2(dxx), gv[12]);
-        gv[13] = fma2(hh, bc2(dx) * dy[q], gv[13]);
-        gv[14] = fma2(hh, dy[q] * dy[q], gv[14]);
-        gv[15] += u;
+        const f2 hq = bc2(B.y) * u;   // h = opacity * u: the moments are h's (rg_streams.inc)
+        const f2 uy = hq * dy[q];
+        const f2 ex = fma2(dy[q], bc2(A.w), bc2(dxcx));    // the conic applied to (dx, dy)
+        const f2 ey = fma2(dy[q], bc2(B.x), bc2(b_xy));
+        const f2 tt = fma2(__builtin_elementwise_abs(ey), cH, __builtin_elementwise_abs(ex) * cW);
+        s_u += u; s_h += hq; s_uy += uy;
+        s_uyy = fma2(uy, dy[q], s_uyy);
+        s_ab = fma2(__builtin_elementwise_abs(hq), tt, s_ab);
       }
       const uint64_t contrib_mask = __ballot(contributed);
       if (contrib_mask == 0) continue;
       float gs[REC];
+      gs[0] = s_col[0][0] + s_col[0][1]; gs[1] = s_col[1][0] + s_col[1][1]; gs[2] = s_col[2][0] + s_col[2][1];
+      gs[3] = s_dt[0] + s_dt[1]; gs[4] = gs[3] * dx; gs[5] = s_dty[0] + s_dty[1];
+      gs[6] = s_nrm[0][0] + s_nrm[0][1]; gs[7] = s_nrm[1][0] + s_nrm[1][1]; gs[8] = s_nrm[2][0] + s_nrm[2][1];
+      gs[15] = s_u[0] + s_u[1];
+      gs[9] = (s_h[0] + s_h[1]) * dx; gs[10] = s_uy[0] + s_uy[1]; gs[11] = s_ab[0] + s_ab[1];
+      gs[12] = gs[9] * dx; gs[13] = gs[10] * dx; gs[14] = s_uyy[0] + s_uyy[1];
+      if constexpr (COORD) {
 #pragma unroll
-      for (int i = 0; i < REC; i++) gs[i] = gv[i][0] + gv[i][1];
-      const float tot = wave_reduce_scatter<REC>(gs, lane);
-      if (lane < (COORD ? 25 : 16)) unsafeAtomicAdd(a.acc + (size_t)gid * REC + lane, tot);
+        for (int c = 0; c < 3; c++) { gs[16 + c] = s_co[c][0] + s_co[c][1]; gs[19 + 2 * c] = gs[16 + c] * dx; gs[20 + 2 * c] = s_coy[c][0] + s_coy[c][1]; }
+#pragma unroll
+        for (int c = 25; c < 32; c++) gs[c] = 0.f;
+      }
+      // rows first (one DPP stage + wave-private LDS: row_reduce16), then the four rows' totals of component (lane & 15)
+      float tot = row_reduce16(*reinterpret_cast<float (*)[16]>(gs), red);
+      tot += __shfl_xor(tot, 16);
+      tot += __shfl_xor(tot, 32);
+      if constexpr (REC == 32) {
+        float tot1 = row_reduce16(*reinterpret_cast<float (*)[16]>(gs + 16), red);
+        tot1 += __shfl_xor(tot1, 16);
+        tot1 += __shfl_xor(tot1, 32);
+        if (lane >= 16 && lane < 25) unsafeAtomicAdd(a.acc + (size_t)gid * REC + lane, tot1);
+      }
+      if (lane < 16) unsafeAtomicAdd(a.acc + (size_t)gid * REC + lane, tot);
     }
   }
 }
@@ -1258,7 +1336,6 @@ struct PreBwdArgs {
   int acc_raw;                // components 9..14 of the records are raw moments of u = G dL/dalpha (blend_bwd_streams_kernel, rg_streams.inc):
                               // the mean2D / conic sums are formed here, once per Gaussian; 2: and the record is written back in the
                               // reference's form (debugging / tests: RadegsBwdArgs::keep_sums)
-  const float4* splat_b;      // coord-map modes: camera planes, for the mean2D sums of a raw record
   float* acc_out;             // acc_raw == 2: where the converted record goes (the accumulator itself)
   int acc_rezero;             // clear every consumed record (RadegsBwdArgs::acc_reuse): the accumulator goes back to its owner all zeros
   int vec_slab;               // the SH slab moves in 16-byte pieces (3M % 4 == 0, 3M <= 48, shs and dL_dsh 16-byte aligned)
@@ -1340,17 +1417,12 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
   int radius = 0;
   unsigned cflags = 0;
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0, rq = r0;
-  float4 sa0 = r0, sa1 = r0, sa2 = r0, sa3 = r0, sb0 = r0, sb1 = r0;
   float r6 = 0.f, m0 = 0.f, m1 = 0.f, m2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
   if (live) {
     radius = a.radii[idx];
     const float4* r = reinterpret_cast<const float4*>(a.acc + i * a.rec);
     r0 = r[0]; r1 = r[1]; r2 = r[2]; r3 = r[3];
     if (a.rec == 32) { r4 = r[4]; r5 = r[5]; r6 = r[6].x; }
-    if (a.acc_raw) {   // the Gaussian's blend record (conic, opacity, depth plane) for the raw moments' coefficients: requested with the rest
-      sa0 = a.splat_a[4 * i]; sa1 = a.splat_a[4 * i + 1]; sa2 = a.splat_a[4 * i + 2]; sa3 = a.splat_a[4 * i + 3];
-      if (a.rec == 32) { sb0 = a.splat_b[3 * i]; sb1 = a.splat_b[3 * i + 1]; }
-    }
     if (a.acc_rezero && radius > 0) {   // only a visible Gaussian's record can have been touched (it is in no list otherwise)
       float4* w = reinterpret_cast<float4*>(a.acc_out + i * a.rec);
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1407,24 +1479,7 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
 #pragma unroll
         for (int c = 0; c < 6; c++) acc.dcp[c] = 0.f;
       }
-      if (a.acc_raw) {   // raw moments -> the reference's sums (backward.cu:981-1012; layout: rg_streams.inc)
-        const float cx = sa0.z, cy = sa0.w, cz = sa1.x, op = sa1.y, rpx = sa2.w, rpy = sa3.x;
-        const float sux = acc.dmean2D[0], suy = acc.dmean2D[1];
-        float mx2 = fmaf(rpx, acc.dts, -op * fmaf(cx, sux, cy * suy));
-        float my2 = fmaf(rpy, acc.dts, -op * fmaf(cy, sux, cz * suy));
-        if (a.rec == 32) {
-          mx2 = fmaf(acc.dvp[0], sb0.x, fmaf(acc.dvp[1], sb0.z, fmaf(acc.dvp[2], sb1.x, mx2)));
-          my2 = fmaf(acc.dvp[0], sb0.y, fmaf(acc.dvp[1], sb0.w, fmaf(acc.dvp[2], sb1.y, my2)));
-        }
-        acc.dmean2D[0] = mx2; acc.dmean2D[1] = my2; acc.dmean2D[2] *= fabsf(op);
-        const float hop = -0.5f * op;
-        acc.dconic[0] *= hop; acc.dconic[1] *= hop; acc.dconic[2] *= hop;
-        if (a.acc_raw == 2) {
-          float4* w = reinterpret_cast<float4*>(a.acc_out + i * a.rec);
-          w[2] = make_float4(r2.x, acc.dmean2D[0], acc.dmean2D[1], acc.dmean2D[2]);
-          w[3] = make_float4(acc.dconic[0], acc.dconic[1], acc.dconic[2], acc.dop);
-        }
-      }
+      acc.raw = a.acc_raw != 0;   // components 9..14 are raw moments (rg_streams.inc): preprocess_bwd() turns them into the reference's sums
       // constant factors the blend backward left out of its sums (linear, so they commute with the sum):
       // 1/focal on the plane gradients (backward.cu:917-922,939-940), W/2 and H/2 on mean2D (:1002-1003)
       if (!a.acc_final) {
@@ -1432,7 +1487,7 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
         acc.drp[0] *= ifx; acc.drp[1] *= ify;
 #pragma unroll
         for (int c = 0; c < 3; c++) { acc.dcp[2 * c] *= ifx; acc.dcp[2 * c + 1] *= ify; }
-        acc.dmean2D[0] *= 0.5f * cam.W; acc.dmean2D[1] *= 0.5f * cam.H;
+        acc.half_wh = true;   // W/2, H/2 on mean2D are applied by preprocess_bwd() (after a raw record's conversion)
       }
       float sc3[3] = {s0, s1, s2}, rq4[4] = {rq.x, rq.y, rq.z, rq.w};
       float cov[6];
@@ -1444,7 +1499,8 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
       }
       // what the reference's computeCov2DCUDA reads as `conic_opacity[idx].w` is dL_dconic[idx].w (argument slip at
       // rasterizer_impl.cu:568); the stored opacity*coef only with opacity_grad_intended (include/radegs.h)
-      const float op_combined = a.opacity_grad_intended ? (a.acc_raw ? sa1.y : a.splat_a[4 * i + 1].y) : acc.dconic[2];
+      // (a raw record holds sum h dy dy there: dL_dconic.w = -1/2 of it, rg_streams.inc)
+      const float op_combined = a.opacity_grad_intended ? a.splat_a[4 * i + 1].y : (a.acc_raw ? -0.5f * acc.dconic[2] : acc.dconic[2]);
       if (row) {  // rows beyond the active degree stay zero
         const int K = (a.D + 1) * (a.D + 1);
         for (int c = K * 3; c < rowf; c++) row[c] = 0;
@@ -1453,9 +1509,14 @@ __global__ void __launch_bounds__(kPreBwdThreads) preprocess_bwd_kernel(const Pr
       o.dscale[0] = o.dscale[1] = o.dscale[2] = 0; o.drot[0] = o.drot[1] = o.drot[2] = o.drot[3] = 0;
       preprocess_bwd(mk3(m0, m1, m2), has_sr ? sc3 : nullptr, has_sr ? rq4 : nullptr, cov, op_combined, a.D, row,
                      cflags & 7u, cam, acc, row, o);
+      if (a.acc_raw == 2) {   // RadegsBwdArgs::keep_sums: the record goes back in the reference's form (before the W/2, H/2 factors)
+        float4* w = reinterpret_cast<float4*>(a.acc_out + i * a.rec);
+        w[2] = make_float4(r2.x, o.sums_mean2D[0], o.sums_mean2D[1], o.sums_mean2D[2]);
+        w[3] = make_float4(o.sums_conic[0], o.sums_conic[1], o.sums_conic[2], acc.dop);
+      }
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        a.dL_dmean2D[3 * i + c] = acc.dmean2D[c];
+        a.dL_dmean2D[3 * i + c] = o.dmean2D[c];
         a.dL_dcolor[3 * i + c] = acc.dcolor[c];
         a.dL_dmean3D[3 * i + c] = o.dmean3D[c];
         a.dL_dscale[3 * i + c] = o.dscale[c];

@@ -24,9 +24,17 @@ struct SplatAcc {     // sums over all (pixel, this Gaussian) pairs
   float dop;          // d/d (opacity*coef)
   float dvp[3];       // d/d view-space mean (coord map)
   float dcp[6];       // d/d camera_plane    (already divided by focal, backward.cu:917-922)
+  // how the blend backward left the record (csrc/rg_streams.inc), both false for a record in the reference's own form:
+  bool raw = false;      // dmean2D[0..1] and dconic[0..2] are RAW MOMENTS of h = opacity G dL/dalpha about the Gaussian's centre (sum h dx,
+                         // sum h dy | sum h dx dx, sum h dx dy, sum h dy dy): the reference's sums are linear in them with coefficients this
+                         // function derives anyway (the conic, the depth / camera planes), so they are formed here, once per Gaussian
+  bool half_wh = false;  // the W/2, H/2 factors of dL_dmean2D (backward.cu:1002-1003) have not been applied yet
 };
 
 struct SplatBwd {
+  float dmean2D[3];      // the returned dL_dmean2D row (x, y signed; z = abs-gradient)
+  float sums_mean2D[3];  // the record's mean2D / conic sums in the reference's form (before W/2, H/2): what a raw record converts to
+  float sums_conic[3];
   float dmean3D[3];
   float dopacity;
   float dcov3D[6];
@@ -182,6 +190,7 @@ RG_HD void preprocess_bwd(v3 mean, const float* scale3, const float* quat4, cons
   m3 dL_dVrk = zero33(), dL_dnJ = zero33();
   v3 plane = mk3(0, 0, 0);
   float dL_du, dL_dv, dL_dl, l, nl;
+  float cplx[3] = {0.f, 0.f, 0.f}, cply[3] = {0.f, 0.f, 0.f};   // camera planes without 1/focal (zero in the degenerate branch, as the forward's)
   if (g.uvh_mn.x != g.uvh_mn.x || g.D == 0) {  // backward.cu:262-272
     nl = 1; l = 1; dL_du = 0; dL_dv = 0; dL_dl = 0;
   } else {
@@ -199,6 +208,7 @@ RG_HD void preprocess_bwd(v3 mean, const float* scale3, const float* quat4, cons
     const float cpl0x = (-(v2 + 1) * t.z + plane.x * t.x) / nl, cpl0y = (uv * t.z + plane.y * t.x) / nl;
     const float cpl1x = (uv * t.z + plane.x * t.y) / nl, cpl1y = (-(u2 + 1) * t.z + plane.y * t.y) / nl;
     const float cpl2x = (t.x + plane.x * t.z) / nl, cpl2y = (t.y + plane.y * t.z) / nl;
+    cplx[0] = cpl0x; cplx[1] = cpl1x; cplx[2] = cpl2x; cply[0] = cpl0y; cply[1] = cpl1y; cply[2] = cpl2y;
     const float rplx = plane.x * factor_normal, rply = plane.y * factor_normal;
     v3 ray_n = mk3(-plane.x * factor_normal, -plane.y * factor_normal, -1.0f);
     v3 cam_n = mul(nJ, ray_n);
@@ -255,7 +265,22 @@ RG_HD void preprocess_bwd(v3 mean, const float* scale3, const float* quat4, cons
   const float denom = ca * cc - cb * cb;
   float dL_da = 0, dL_db = 0, dL_dc = 0;
   const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-  const float dcx = a.dconic[0], dcy = a.dconic[1], dcz = a.dconic[2];
+  // the blend backward's mean2D / conic sums -- from a raw record: the moments times the coefficients of backward.cu:981-1012
+  float dcx = a.dconic[0], dcy = a.dconic[1], dcz = a.dconic[2];
+  float gx2 = a.dmean2D[0], gy2 = a.dmean2D[1];
+  if (a.raw) {
+    const float idet = 1.0f / denom;                              // the conic as the forward forms it (rg_preprocess.h: cvz / det, ...)
+    const float kx = cc * idet, ky = -cb * idet, kz = ca * idet;
+    const float shx = a.dmean2D[0], shy = a.dmean2D[1];
+    const float rfac = l / nl;                                    // ray plane = plane * l / nl / focal (0 in the degenerate branch)
+    gx2 = -(kx * shx + ky * shy) + (plane.x * rfac * a.dts + (cplx[0] * a.dvp[0] + cplx[1] * a.dvp[1] + cplx[2] * a.dvp[2])) / h_x;
+    gy2 = -(ky * shx + kz * shy) + (plane.y * rfac * a.dts + (cply[0] * a.dvp[0] + cply[1] * a.dvp[1] + cply[2] * a.dvp[2])) / h_y;
+    dcx = -0.5f * a.dconic[0]; dcy = -0.5f * a.dconic[1]; dcz = -0.5f * a.dconic[2];
+  }
+  o.sums_mean2D[0] = gx2; o.sums_mean2D[1] = gy2; o.sums_mean2D[2] = a.dmean2D[2];
+  o.sums_conic[0] = dcx; o.sums_conic[1] = dcy; o.sums_conic[2] = dcz;
+  if (a.half_wh) { gx2 *= 0.5f * (float)cam.W; gy2 *= 0.5f * (float)cam.H; }
+  o.dmean2D[0] = gx2; o.dmean2D[1] = gy2; o.dmean2D[2] = a.dmean2D[2];
   float* dcov = o.dcov3D;
   o.dopacity = a.dop;
   if (denom2inv != 0) {
@@ -322,7 +347,6 @@ RG_HD void preprocess_bwd(v3 mean, const float* scale3, const float* quat4, cons
   const float m_w = 1.0f / (m_hw + 0.0000001f);
   const float mul1 = (pj[0] * mean.x + pj[4] * mean.y + pj[8] * mean.z + pj[12]) * m_w * m_w;
   const float mul2 = (pj[1] * mean.x + pj[5] * mean.y + pj[9] * mean.z + pj[13]) * m_w * m_w;
-  const float gx2 = a.dmean2D[0], gy2 = a.dmean2D[1];
   const float d1x = (pj[0] * m_w - pj[3] * mul1) * gx2 + (pj[1] * m_w - pj[3] * mul2) * gy2;
   const float d1y = (pj[4] * m_w - pj[7] * mul1) * gx2 + (pj[5] * m_w - pj[7] * mul2) * gy2;
   const float d1z = (pj[8] * m_w - pj[11] * mul1) * gx2 + (pj[9] * m_w - pj[11] * mul2) * gy2;

@@ -194,6 +194,9 @@ def library():
 
 def _check(rc, what):
     if rc < 0:
+        # whatever failed, the cached accumulation scratches are no longer known to be zero (RADEGS_ERR_STATE in particular is reported
+        # one call late: the backward it belongs to has poisoned its scratch with NaN): the next backward starts from a fresh one
+        _ACC_SCRATCH.clear()
         raise RuntimeError(f"{what} failed ({rc}): {library().radegs_last_error().decode()}")
     return rc
 
@@ -237,6 +240,7 @@ _POISON = os.environ.get("RADEGS_DEBUG_POISON", "0") == "1"
 # RADEGS_ACC_REUSE=0: a fresh accumulation scratch per backward, filled with zeros by the call (the behaviour before round 6); default:
 # one scratch per (device, stream), handed back zeroed by the backward itself (RadegsBwdArgs.acc_reuse)
 ACC_REUSE = os.environ.get("RADEGS_ACC_REUSE", "1") != "0"
+ACC_REUSE_MAX_BYTES = 256 << 20
 
 
 class _Resizable:
@@ -432,7 +436,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         # (RadegsBwdArgs.acc_reuse) -- unless its contents are wanted afterwards (KEEP_ACC), which takes a scratch of its own
         abytes = P * (128 if require_coord else 64)
         akey = (dev.index if dev.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream(dev).cuda_stream))
-        acc_cached = None if (KEEP_ACC or _POISON or not ACC_REUSE) else _acc_scratch(akey, abytes, dev)
+        # (above ACC_REUSE_MAX_BYTES the clearing stores cost the per-Gaussian kernel more than the fill they replace: C4, 5 M Gaussians with
+        # the coord map = 640 MB, same-box A/B: preprocess_bwd +0.13 ms against a 0.08-ms fill)
+        acc_cached = None if (KEEP_ACC or _POISON or not ACC_REUSE or abytes > ACC_REUSE_MAX_BYTES) else _acc_scratch(akey, abytes, dev)
         acc = _Resizable(dev) if acc_cached is None else _Fixed(acc_cached)
         ready_cb, ready_err = None, []
         owner = getattr(grad_alloc, "__self__", None)

@@ -175,8 +175,21 @@ class FactoredGradExchange:
         self._t_first = None      # event on the side stream before the step's first collective (timing)
         self._timings = []        # (first collective issued, exchange() entered, exchange() done) event triples, one per step
 
+    def _abandon_step(self):
+        """Collectives of a step whose exchange() never ran (its backward raised after the hooks had fired, or the caller skipped the
+        exchange): every rank that got as far issued them, so they are waited for -- the side stream and the process group stay in
+        order -- and the step's state is dropped.  The rows they reduced in place belong to a gradient nobody will read."""
+        pending = list(self._chunk_handles) + (list(self._early) if self._early is not None else [])
+        for h in pending:
+            h.wait()
+        self._early, self._chunk_handles, self._rows_done, self._t_first = None, [], 0, None
+
     def set_view(self, campos):
-        """The camera position of the view about to be differentiated: lets drgb_ready() / grads_ready() start the collectives early."""
+        """The camera position of the view about to be differentiated: lets drgb_ready() / grads_ready() start the collectives early.
+        Starts a STEP: whatever an unfinished earlier step left behind is waited for and discarded first (rows all-reduced
+        by a step without exchange() would otherwise be taken for this step's, and the ranks would diverge silently)."""
+        if self._early is not None or self._chunk_handles or self._rows_done:
+            self._abandon_step()
         self._campos = campos.reshape(1, 3).to(torch.float32).contiguous()
 
     @property
@@ -213,6 +226,8 @@ class FactoredGradExchange:
         per-Gaussian backward is not yet): start their all-gather on the side stream."""
         if not self.early_drgb:
             return
+        if self._early is not None:
+            raise RuntimeError("FactoredGradExchange: a second backward before exchange() (or set_view()) finished the first one's step")
         self._early = self._on_side_stream(lambda: (
             dist.all_gather_into_tensor(self.gathered.view(-1, 3), self.drgb, group=self.group, async_op=True),
             dist.all_gather_into_tensor(self.campos_all, self._campos, group=self.group, async_op=True)))
@@ -225,7 +240,12 @@ class FactoredGradExchange:
         """Called by the backward on the host after each launch of its per-Gaussian kernel (include/radegs.h: grads_ready): rows
         [first, first + count) of the small gradient tensors are final once the launch stream reaches this point.  All but the last
         range are all-reduced from here, under the launches that follow; the last one leaves with exchange()."""
-        if not self.early_grads or first != self._rows_done or first + count >= self.P:
+        if not self.early_grads:
+            return
+        if first == 0 and self._rows_done != 0:
+            raise RuntimeError("FactoredGradExchange: a second backward before exchange() (or set_view()) finished the first one's step: "
+                               f"rows [0, {self._rows_done}) are already on their way")
+        if first != self._rows_done or first + count >= self.P:
             return
         self._chunk_handles += self._on_side_stream(lambda: self._allreduce_rows(first, count))
         self._rows_done = first + count

@@ -25,6 +25,8 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- p
 find $OUT/kt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 timeout 300 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_tcc --output-format csv -- python $B --steps 9 --warmup 9 --no-cpu-baseline --no-other-configs > $OUT/pmc_tcc.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVES -d $OUT/pmc_sq --output-format csv -- python $B --steps 9 --warmup 9 --no-cpu-baseline --no-other-configs > $OUT/pmc_sq.log 2>&1
+# third pass (round 6): the kernel's own clock (GRBM_GUI_ACTIVE, summed over the 8 XCDs) and the LDS side -- what scripts/valu_busy.py needs
+timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_ANY -d $OUT/pmc_clk --output-format csv -- python $B --steps 9 --warmup 9 --no-cpu-baseline --no-other-configs > $OUT/pmc_clk.log 2>&1
 find $OUT -name "*counter_collection.csv" | while read f; do d=$(basename $(dirname $(dirname $f))); cp $f $OUT/${d}_counters.csv; done
-rm -rf $OUT/kt $OUT/pmc_tcc $OUT/pmc_sq
+rm -rf $OUT/kt $OUT/pmc_tcc $OUT/pmc_sq $OUT/pmc_clk
 ls $OUT

@@ -22,7 +22,7 @@ with open(os.path.join(dst, f"{tag}_rocprofv3_kernel_stats.csv"), "w", newline="
     for r in rows:
         w.writerow(r)
 out = {}
-for name in ("pmc_sq", "pmc_tcc"):
+for name in ("pmc_sq", "pmc_tcc", "pmc_clk"):
     p = os.path.join(src, name + "_counters.csv")
     if not os.path.exists(p):
         continue

@@ -173,6 +173,29 @@ def _factored_worker(rank, world, port, out_dir):
         assert torch.equal(out_chunked[k], out[k]), k
     assert bool((out_chunked["densify_stats"] == float(sum(range(1, world + 1)))).all()) and bool((out_chunked["radii_max"] == world + 4).all())
     assert ex._chunk_handles == [] and ex._rows_done == 0
+    # a step whose exchange() never ran (its backward raised after the hooks had fired) must not leak into the next one.
+    # The hooks of an abandoned step fire on both ranks; a second backward without exchange() / set_view() in between is refused; the next
+    # set_view() waits for the abandoned collectives and starts from row 0 again -- the step after it gives the reference result.
+    ex.set_view(campos)
+    ex.drgb_ready()
+    ex.small.copy_(small_before)
+    ex.grads_ready(0, 128)
+    assert ex._rows_done == 128
+    for hook in (lambda: ex.grads_ready(0, 128), ex.drgb_ready):
+        try:
+            hook()
+            raise AssertionError("a second backward inside one step was accepted")
+        except RuntimeError as e:
+            assert "second backward" in str(e)
+    ex.set_view(campos)                          # abandons the step above
+    assert ex._rows_done == 0 and ex._chunk_handles == [] and ex._early is None
+    ex.drgb_ready()
+    ex.small.copy_(small_before)                 # (the abandoned all-reduce had summed rows [0, 128) in place)
+    ex.grads_ready(0, 128)
+    ex.grads_ready(128, P - 128)
+    out_after = ex.exchange(means3D, campos, average=True)
+    for k in out:
+        assert torch.equal(out_after[k], out[k]), k
     torch.save({"out": {k: v.clone() for k, v in out.items()}, "small": small_before, "drgb": drgb, "campos": campos, "means3D": means3D},
                os.path.join(out_dir, f"f{rank}.pt"))
     dist.barrier()

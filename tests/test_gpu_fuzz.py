@@ -1,13 +1,13 @@
 """Randomised parity sweep: scene density, image shapes that are not multiples of the tile, SH degree, 2D-filter size,
 output modes, background colour, scale_modifier, camera pose, opacity regime -- forward indices exact, images within
-tolerance, gradients by the criteria of test_gpu_parity.check_backward: the standard ones for scenes of at least 2 000 Gaussians,
-widened noise factors below (short, cancelling per-Gaussian sums).  Seeds are fixed, so a failure reproduces."""
+tolerance, gradients against the float64 oracle with the reference's own arithmetic as the yardstick (tests/arbiter.py): one
+criterion for every scene size.  Seeds are fixed, so a failure reproduces."""
 import numpy as np
 import pytest
 import torch
 
 from synth_scene import make_scene
-from test_gpu_parity import check_backward, check_forward
+from test_gpu_parity import check_forward
 
 pytestmark = pytest.mark.gpu
 
@@ -26,30 +26,32 @@ def _config(seed):
 
 import os  # noqa: E402
 
-# RADEGS_FUZZ_SEEDS="a:b" (or "s1,s2,...") widens the sweep, e.g. 14:214 for a one-off bug hunt; the default 14 run in ~20 s
-_SPEC = os.environ.get("RADEGS_FUZZ_SEEDS", "0:14")
-_SEEDS = [int(v) for v in _SPEC.split(",")] if "," in _SPEC else list(range(*(int(v) for v in _SPEC.split(":"))))
-
-
-# Gradient criteria of the sweep (check_backward) as a FUNCTION OF SCENE SIZE.  Scenes of at least 2 000 Gaussians run the standard
-# criteria of test_gpu_parity.py -- >= 99 % of every tensor's elements inside the strict 1e-5 / 1e-4 bar, the rest inside the fp32 noise
-# band; against the fp64 oracle at most 1.1x the fp32 oracle's own rms error and 1.25x its max error.  Below that the statistics
-# themselves are noisy (the fp32 oracle's error is ONE random draw of rounding over a few hundred short, cancelling sums, the HIP
-# path's another): 0.97 / 4x band / 1.5x rms / 2x max.  The split is the measured one: of 40 seeds at the standard criteria the four
-# that fail have 306, 627, 961 and 1 261 Gaussians, and they fail identically with a build whose blend backward uses the specified
-# exponential and an IEEE division (profiles/r03_fuzz_table_*.txt).  RADEGS_FUZZ_THRESH overrides both (experiments).
-_STANDARD, _SMALL_SCENE, _SMALL_BELOW = (0.99, 1.1, 1.25, 1.0), (0.97, 1.5, 2.0, 4.0), 2000
-_FORCED = [float(v) for v in os.environ["RADEGS_FUZZ_THRESH"].split(",")] if os.environ.get("RADEGS_FUZZ_THRESH") else None
+# The default sweep: seeds 0..39 plus the scenes round 5's sweep of 400 singled out -- the sixteen scenes of at least 2 000 Gaussians that
+# missed that round's "standard" criteria (almost all 0.7-px splats) and the three small ones with the largest deviations.  ~1.3 s each.
+# RADEGS_FUZZ_SEEDS="a:b" (or "s1,s2,...") replaces the list, e.g. 0:400 for a one-off hunt.
+_DEFAULT = list(range(40)) + [47, 75, 106, 118, 152, 211, 220, 241, 242, 250, 256, 280, 289, 310, 340, 378] + [44, 54, 329, 22]
+_SPEC = os.environ.get("RADEGS_FUZZ_SEEDS", "")
+_SEEDS = _DEFAULT if not _SPEC else ([int(v) for v in _SPEC.split(",")] if "," in _SPEC or ":" not in _SPEC else list(range(*(int(v) for v in _SPEC.split(":")))))
 
 
 def _run(seed):
+    """Forward: exact indices, maps at 1e-5 / 1e-4 (check_forward).  Backward: ONE criterion for every scene size and tensor -- the product
+    is as close to the exact (float64) gradient as the reference's own arithmetic is, and agrees with the reference wherever the
+    reference's fp32 value is itself well-conditioned (tests/arbiter.py: criteria A-D, constants from profiles/r06_arbiter_table_*.txt).
+    Rounds 2-5 used ">= 99 % strict + noise band" with looser numbers below 2 000 Gaussians; the table showed why that cannot hold on
+    sub-pixel scenes of ANY size: the reference's own fp32 sums miss the exact value by a quarter of the tolerance on up to 43 % of the
+    elements there."""
+    import arbiter
+    from synth_scene import upstream_grads
     kw, scale_modifier = _config(seed)
     if kw["mu_px"] >= 12.0:
         kw["P"] = min(kw["P"], 2500)  # heavy overdraw: keep the oracle's backward in seconds
     s = make_scene(**kw)
-    o, h = check_forward(s, scale_modifier=scale_modifier)
-    t = _FORCED or (_STANDARD if kw["P"] >= _SMALL_BELOW else _SMALL_SCENE)
-    check_backward(s, o, seed=seed, min_strict=t[0], scale_modifier=scale_modifier, rms_factor=t[1], max_factor=t[2], band_factor=t[3])
+    check_forward(s, scale_modifier=scale_modifier)
+    info, rows = arbiter.evaluate(s, upstream_grads(s, seed), scale_modifier=scale_modifier)
+    bad = {k: arbiter.failed_criteria(v, worst_element=info["same_decisions"]) for k, v in rows.items()}
+    bad = {k: v for k, v in bad.items() if v}
+    assert not bad, (seed, kw, {k: [(c, float(m), float(a)) for c, m, a in v] for k, v in bad.items()})
 
 
 @pytest.mark.parametrize("seed", _SEEDS)
@@ -58,9 +60,9 @@ def test_random_configuration(seed):
 
 
 @pytest.mark.parametrize("streams", [0, 1])
-@pytest.mark.parametrize("seed", [14, 15, 16, 17, 18, 19])
+@pytest.mark.parametrize("seed", [14, 15, 16, 17, 18, 19, 106, 241])
 def test_random_configuration_forced_blend_path(seed, streams, monkeypatch):
     """The launcher picks tile-wide kernels or sub-tile entry streams by splat size; here each is forced on scenes it would not
-    have been picked for (big splats through the streams, tiny ones through the tile-wide walk)."""
+    have been picked for (big splats through the streams, tiny ones -- two sub-pixel scenes among them -- through the tile-wide walk)."""
     monkeypatch.setenv("RADEGS_STREAMS", str(streams))
     _run(seed)

@@ -312,8 +312,12 @@ def test_stream_backward_on_an_overwritten_image_state_reports_an_error_instead_
     good = [t.clone() for t in backward(fw) if t is not None]
     fw = forward()
     fw[11].zero_()                       # the image state, tag included, is gone
-    backward(fw)                         # queues the stream backward on it: no trap, no exception yet
+    bad = backward(fw)                   # queues the stream backward on it: no trap, no exception yet ...
     torch.cuda.synchronize(dev)
+    # ... but nothing a caller could mistake for a gradient either: the kernel poisons the accumulator, every visible
+    # Gaussian's row comes back NaN -- the error itself is only reported by the NEXT call, which may be somebody else's
+    vis = fw[8] > 0
+    assert bool(vis.any()) and all(bool(torch.isnan(t[vis]).all()) for t in (bad[0], bad[3]))   # dL_dmeans2D, dL_dmeans3D
     with pytest.raises(RuntimeError, match="does not hold the entry streams"):
         forward()                        # the next call into the library on this thread reports it ...
     fw = forward()                       # ... once; the context is alive and the following calls are right again
@@ -481,6 +485,31 @@ def test_stream_byte_budget_falls_back_to_the_tile_wide_kernels(monkeypatch):
     check_backward(s, o, seed=66)
 
 
+def test_a_view_that_exceeded_the_stream_budget_does_not_ban_the_streams_for_ever(monkeypatch):
+    """one view whose lists exceed RADEGS_STREAMS_MAX_MB (a densification peak before pruning) makes the launcher stop asking for
+    entry streams at that (device, W, H) -- for 64 forwards, not for the rest of the run: afterwards they are tried again."""
+    import diff_gaussian_rasterization._C as C
+    from gpu_util import HipRun
+    monkeypatch.setenv("RADEGS_SPECULATE", "1")
+    s = make_scene(20000, 344, 216, sh_degree=0, mu_px=1.5, seed=72, kernel_size=0.0, require_coord=False, require_depth=True)
+    for _ in range(2):                                  # history for this (device, W, H): the next forwards are speculative
+        HipRun(s, _dev()).forward_native()
+    assert C.last_forward_used_streams() is True
+    monkeypatch.setenv("RADEGS_STREAMS_MAX_MB", "1")    # now the lists (a few MB) exceed the budget: noticed by a speculative forward
+    ref = [t.clone() for t in HipRun(s, _dev()).forward_native()[1:9]]
+    assert C.last_forward_used_streams() is False       # redone through the tile-wide kernels
+    monkeypatch.delenv("RADEGS_STREAMS_MAX_MB")         # the budget is back (the peak is over) ...
+    back = None
+    for n in range(1, 80):
+        out = HipRun(s, _dev()).forward_native()
+        for a, b in zip(out[1:9], ref):                 # either formulation: same maps (1e-5 / 1e-4), same radii
+            assert torch.equal(a, b) if a.dtype != torch.float32 else torch.allclose(a, b, rtol=RTOL, atol=ATOL)
+        if C.last_forward_used_streams():
+            back = n
+            break
+    assert back is not None and back > 8, back          # ... refused for a while, then tried again and kept
+
+
 @pytest.mark.parametrize("coord,depth", [(False, True), (True, True)])
 def test_block_masks_in_the_tile_keys(coord, depth, monkeypatch):
     """Scenes of 2^24 Gaussians and more cannot carry an instance's block mask next to the Gaussian index in the 32-bit value: it rides in
@@ -510,6 +539,7 @@ def test_entry_stream_storage_is_sized_from_the_previous_view_and_an_overflow_is
         os.environ["RADEGS_SPECULATE"] = "0"
         exact = [t.clone() for t in HipRun(s, _dev()).forward_native()[1:9]]
         os.environ["RADEGS_SPECULATE"] = "1"
+        C.binning_stats(reset=True)                  # the counters are process-wide: whatever earlier tests did is not this test's
         for _ in range(3):                           # seed the (device, W, H) history
             h = HipRun(s, _dev()); st = h.forward_native()
         for a, b in zip(st[1:9], exact):
