@@ -39,7 +39,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 # VALU issue peak in wave64 instructions: 256 CUs x 4 SIMDs x 2.4 GHz, one instruction every 2 cycles per SIMD (same guide: "issues each
 # VALU instruction over 2 cycles"; 157.3 TFLOP/s fp32 = this x 64 lanes x 2 flop)
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.3   # 1 024 SIMDs, 2.4 GHz, 2.3 cycles per full-rate wave64 instruction (profiles/r06_valu_calibration.txt)
 
 
 def algorithmic_bytes(P, Pv, R, N, D, c, d):
@@ -446,8 +446,10 @@ def valu_roofline(kernel_name, tag, config, P, W, H, dom_ms):
                 ach = v["SQ_INSTS_VALU"] / (dom_ms * 1e-3) / 1e9
                 return {"bound": "valu", "kernel": kernel_name, "achieved": round(ach, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instructions/s",
                         "frac": round(ach / VALU_PEAK_GINST, 4), "wave_instructions_per_launch": int(v["SQ_INSTS_VALU"]),
-                        "source": os.path.basename(f) + ": SQ_INSTS_VALU per launch (separate --pmc pass); peak = 1024 SIMDs x 2.4 GHz / 2 cycles per "
-                                  "instruction -- half-rate classes (DPP, select, compare: DESIGN 4.3) make 1.0 unreachable"}
+                        "source": os.path.basename(f) + ": SQ_INSTS_VALU per launch (separate --pmc pass); peak = 1024 SIMDs x 2.4 GHz / 2.3 cycles per "
+                                  "full-rate instruction, measured (profiles/r06_valu_calibration.txt); half-rate classes (DPP, select, compare: "
+                                  "4.3 cycles), transcendentals (8.2) and the 2.0-GHz clock under fp32 load make 1.0 unreachable: the kernel's "
+                                  "own busy fraction is in profiles/r06_valu_busy.txt"}
     except Exception:
         return None
     return None

@@ -10,20 +10,24 @@ from oracle import ref
 from synth_scene import make_scene, upstream_grads
 from util import ATOL, close
 
-# ---- the acceptance band of the gradients is an OBSERVED quantity: profiles/r05_grad_parity.json, written on the GPU box by
+# ---- the acceptance band of the gradients is an OBSERVED quantity: profiles/r06_grad_parity.json, written on the GPU box by
 # scripts/gpu_grad_parity.py, holds per config and tensor the distance of the HIP backward from the compiled reference's AND the distance
-# of the reference from itself when its float atomics land in another order (the same code on another number of host threads).  The
-# test accepts a tensor when rms(hip - ref) and the worst element stay within K x the reference's own self-noise.  K is what that file
-# measured, with room for the run-to-run spread of a worst-element statistic: through the entry streams rms <= 2.9x / worst <= 4.1x were
-# observed (C2, C3, C4, both 100k scenes), through the tile-wide kernels (C5: 100-tile splats) 6.8x / 19.9x on dL_dmeans2D -- the
-# reference's self-noise only re-orders its per-tile atomics, the association INSIDE a tile (fixed in the reference, different here) is
-# not in it, and on C5 it is the larger part (5.8e-5 of the tensor's scale at the worst element).
+# of the reference from itself when its float atomics land in another order -- the same code on three numbers of host threads, the
+# LARGEST of the pairs (one pair's worst element is a single extreme value).  The rule, one for every config and path:
+#     a tensor passes when   rms <= 4 x  and  worst element <= 6 x  the reference's own self-noise          (measured: <= 2.4 x / 3.2 x through
+#     the entry streams on C2, C3, C4 and both 100 k scenes)
+#  or when it is inside the ABSOLUTE backstop  worst <= 1e-4 x scale  and  rms <= 1e-6 x scale             (scale = the tensor's largest element).
+# The backstop is what the tile-wide kernels need on C5 (100-tile splats): the reference's self-noise only re-orders its per-tile
+# atomics, while the association INSIDE a tile -- fixed in the reference, different here (per-strip sums, pixel pairs, a row reduction
+# through LDS) -- is not in it: dL_dmeans2D sits at 5.6 x / 12 x that noise, which is 5.8e-5 / 8.8e-8 of the tensor's scale.  That the
+# tile-wide kernels are as ACCURATE as the reference's arithmetic is shown against the float64 oracle at a size it can run
+# (tests/test_gpu_full.py::test_C5_shape_4k_heavy_overdraw_reduced, tests/arbiter.py).
 import json as _json
 import os as _os
-_NOISE_FILE = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "profiles", "r05_grad_parity.json")
+_NOISE_FILE = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "profiles", "r06_grad_parity.json")
 NOISE = _json.load(open(_NOISE_FILE))
-K_STREAMS = dict(rms=4.5, worst=10.0)
-K_TILEWIDE = dict(rms=10.0, worst=30.0)
+K_RMS, K_WORST = 4.0, 6.0
+BACKSTOP_WORST, BACKSTOP_RMS = 1.0e-4, 1.0e-6
 
 
 def _stats(a, b):
@@ -35,14 +39,12 @@ def _stats(a, b):
 
 
 def _within_observed_noise(name, group, k, a, b, streams):
-    """rms and worst element of (a - b), in units of b's scale, against K x the reference's self-noise for this config and tensor"""
+    """rms and worst element of (a - b), in units of b's scale, against the rule above; the strict fraction at most 1 % below the reference's own"""
     noise = NOISE[name][group][k]["ref_vs_ref"]
-    K = K_STREAMS if streams else K_TILEWIDE
     st = _stats(a, b)
-    assert st["rms"] <= K["rms"] * noise["rms"] + 1e-9, (name, group, k, "rms", st, noise)
-    assert st["worst"] <= K["worst"] * noise["worst"] + 1e-6, (name, group, k, "worst element", st, noise)
-    # the strict fraction may fall below the reference's own by the share of elements whose sums cancel to the last bits: 1 % at most,
-    # and never more than 1 % below what the reference manages against itself
+    in_band = st["rms"] <= K_RMS * noise["rms"] + 1e-9 and st["worst"] <= K_WORST * noise["worst"] + 1e-6
+    in_backstop = st["worst"] <= BACKSTOP_WORST and st["rms"] <= BACKSTOP_RMS
+    assert in_band or in_backstop, (name, group, k, "streams" if streams else "tile-wide", st, noise)
     assert st["strict"] >= min(0.99, noise["strict"] - 0.01), (name, group, k, "strict fraction", st, noise)
     return st
 
