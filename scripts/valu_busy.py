@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import isa_mix  # noqa: E402
 
-C_FULL, C_HALF, C_QUARTER, SIMDS, XCDS = 2.3, 4.3, 8.2, 1024, 8
+C_FULL, C_HALF, C_QUARTER, SIMDS, XCDS = 2.3, 4.3, 8.2, 1024, 8   # profiles/r06_valu_calibration.txt: 2.27-2.33 / 4.18-4.53 / 8.18-8.22
 tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_per_kernel.json")))
 KERNELS = {   # PMC name -> substring of the mangled name
@@ -47,6 +47,7 @@ def half_share(parts):
 
 
 print(f"# {tag}: per launch.  busy = VALU pipe cycles of the issued instructions / the kernel's own cycles (GRBM_GUI_ACTIVE / 8); see the docstring of scripts/valu_busy.py")
+print("# The class costs carry the calibration's spread (+-3 %) and the half-rate share is a static one: read 0.95-1.05 as 'issue-bound'.")
 print(f"# {'kernel':48s} {'Minstr':>8s} {'quarter M':>9s} {'half share':>10s} {'kcycles':>9s} {'clock GHz':>9s} {'busy':>6s}")
 rows = []
 for k, v in pmc.items():
@@ -67,5 +68,5 @@ try:
 except OSError:
     pass
 for cyc, k, mi, mq, h, kc, busy in sorted(rows, reverse=True):
-    ghz = ("%.2f" % (cyc / dur[k])) if k in dur else "-"
+    ghz = ("%.2f" % (cyc / dur[k])) if (k in dur and dur[k] > 50e3) else "-"   # (GRBM_GUI_ACTIVE includes a launch's ramp: meaningless for 5-40 us kernels)
     print(f"{k:50s} {mi:8.2f} {mq:9.2f} {h:>10s} {kc:9.1f} {ghz:>9s} {busy:6.2f}")
