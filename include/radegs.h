@@ -72,12 +72,15 @@ typedef struct RadegsFwdArgs {
   int prefiltered;              /* must be 0 */
   int require_coord, require_depth, debug;
   float* out_color;             /* [3,H,W] */
-  float* out_coord;             /* [3,H,W]  written iff require_coord */
-  float* out_mcoord;            /* [3,H,W]  written iff require_coord */
-  float* out_depth;             /* [1,H,W]  written iff require_depth */
-  float* out_mdepth;            /* [1,H,W]  written iff require_depth */
+  /* The five maps below are PRODUCED iff their flag is set.  A map the flags do not produce is all-zero in the reference
+   * (torch::full(0), DGR/rasterize_points.cu:71-77): when its pointer is non-NULL the forward ZERO-FILLS it (every pixel, inside the
+   * blend kernel -- no separate fill); pass NULL for a map you do not want touched. */
+  float* out_coord;             /* [3,H,W]  produced iff require_coord */
+  float* out_mcoord;            /* [3,H,W]  produced iff require_coord */
+  float* out_depth;             /* [1,H,W]  produced iff require_depth */
+  float* out_mdepth;            /* [1,H,W]  produced iff require_depth */
   float* out_alpha;             /* [1,H,W] */
-  float* out_normal;            /* [3,H,W]  written iff require_coord || require_depth */
+  float* out_normal;            /* [3,H,W]  produced iff require_coord || require_depth */
   int* radii;                   /* [P] */
 } RadegsFwdArgs;
 

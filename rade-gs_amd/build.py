@@ -78,5 +78,46 @@ def build(force=False, verbose=True):
     return LIB
 
 
+TORCH_BINDING_SRC = os.path.join(CSRC, "torch_binding", "radegs_torch_binding.cpp")
+TORCH_BINDING_NAME = "_C_torch"
+
+
+def torch_binding_path():
+    import sysconfig
+    return os.path.join(OUT_DIR, TORCH_BINDING_NAME + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_torch_binding(force=False, verbose=True):
+    """diff_gaussian_rasterization/_C_torch*.so: the reference's pybind `_C` module (DGR/ext.cpp:15-19 -- rasterize_gaussians,
+    rasterize_gaussians_backward, mark_visible, integrate_gaussians_to_points with torch::Tensor arguments) as HOST C++ over the C ABI
+    of libradegs_hip.so.  No device code in it: g++ against the torch / pybind11 / HIP runtime headers, linked to the library next to it
+    ($ORIGIN rpath).  `RADEGS_BINDING=torch` makes the operator package use it instead of the ctypes binding."""
+    import sysconfig
+
+    import torch
+    from torch.utils import cpp_extension as ce
+    lib = build(force=False, verbose=verbose)
+    out = torch_binding_path()
+    header = os.path.join(HERE, "..", "include", "radegs.h")
+    if not (force or _stale(out, [TORCH_BINDING_SRC, header, lib, os.path.abspath(__file__)])):
+        return out
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    inc = ce.include_paths() + [os.path.join(rocm, "include"), sysconfig.get_paths()["include"], os.path.join(HERE, "..", "include")]
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-deprecated-declarations", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_EXTENSION_NAME=" + TORCH_BINDING_NAME, "-DTORCH_API_INCLUDE_EXTENSION_H",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    for i in inc:
+        cmd += ["-isystem", i]
+    cmd += [TORCH_BINDING_SRC, "-o", out, "-L" + tlib, "-L" + OUT_DIR, "-L" + os.path.join(rocm, "lib"), "-lradegs_hip", "-lc10", "-lc10_hip", "-ltorch_cpu",
+            "-ltorch_hip", "-ltorch", "-ltorch_python", "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib, "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    if verbose:
+        print("[radegs build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    if "--torch-binding" in sys.argv:
+        print(build_torch_binding(force="--force" in sys.argv))

@@ -705,6 +705,25 @@ struct BlendFwdArgs {
   const uint32_t* blk_count; const uint32_t* blk_base; uint32_t* blk_consumed; uint32_t* blk_chunks; const uint32_t* blk_order;   // sub-tile entry streams (rg_streams.inc)
 };
 
+// The maps a mode does NOT produce are all-zero in the reference, whatever the flags (torch::full(0), rasterize_points.cu:71-77).  A
+// caller that hands their pointers over gets them zeroed here, by the pixel's own lane in the forward's epilogue -- the stores ride along
+// in a VALU-bound kernel; a separate fill of the 6 unproduced planes of a depth-mode 1080p view was a 9-us kernel + its launch gap per
+// forward.  (NULL: the caller does not want them, or provides zeros itself.)
+template <bool COORD, bool DEPTH>
+__device__ __forceinline__ void zero_unproduced_maps(const BlendFwdArgs& a, size_t pix, size_t HW) {
+  if constexpr (!COORD) {
+    if (a.out_coord) { a.out_coord[pix] = 0.f; a.out_coord[HW + pix] = 0.f; a.out_coord[2 * HW + pix] = 0.f; }
+    if (a.out_mcoord) { a.out_mcoord[pix] = 0.f; a.out_mcoord[HW + pix] = 0.f; a.out_mcoord[2 * HW + pix] = 0.f; }
+  }
+  if constexpr (!DEPTH) {
+    if (a.out_depth) a.out_depth[pix] = 0.f;
+    if (a.out_mdepth) a.out_mdepth[pix] = 0.f;
+  }
+  if constexpr (!COORD && !DEPTH) {
+    if (a.out_normal) { a.out_normal[pix] = 0.f; a.out_normal[HW + pix] = 0.f; a.out_normal[2 * HW + pix] = 0.f; }
+  }
+}
+
 // blockIdx -> work item such that each XCD (block b runs on XCD b % 8) owns a contiguous band.
 __device__ __forceinline__ int xcd_band_remap(int b, int n) {
   const int q = n >> 3, r = n & 7, xcd = b & 7, loc = b >> 3;
@@ -877,6 +896,7 @@ __global__ void __launch_bounds__(64) blend_fwd_kernel(const BlendFwdArgs a) {
     a.out_color[HW + pix] = fmaf(T[s], a.bg[1], Cg[s]);
     a.out_color[2 * HW + pix] = fmaf(T[s], a.bg[2], Cb[s]);
     a.out_alpha[pix] = weight[s];
+    zero_unproduced_maps<COORD, DEPTH>(a, pix, HW);
     if constexpr (COORD) {
 #pragma unroll
       for (int c = 0; c < 3; c++) {

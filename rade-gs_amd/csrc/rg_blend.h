@@ -19,9 +19,15 @@ namespace rg {
 // exp_spec(x) for x <= ~0:  k = rint(x*log2e);  r = x - k*ln2 (two-step Cody-Waite, fma);
 // degree-5 polynomial (Cephes expf coefficients) in fma form;  result * 2^k through the
 // exponent field.  x < -87 returns 0.  <= 1 ulp from expf on [-87, 0].
+// k = rint(x*log2e) WITHOUT v_rndne / v_cvt (both half rate on gfx950): for |t| < 2^22, t + 1.5*2^23 lies in [2^23, 2^24), where
+// one ulp is 1, so the addition itself rounds t to the nearest integer, ties to even (the constant is even) -- the same value rintf(t)
+// gives; subtracting the constant is exact, and the integer k sits in the low mantissa bits of the sum.  Bit-identical to the rintf /
+// (int32_t) form the oracle spells (tests/test_hostcheck.py compares the two over the whole argument range).
+constexpr float kExpMagic = 12582912.0f;
 RG_HD float exp_spec(float x) {
   if (x < -87.0f) return 0.0f;
-  const float kf = rintf(x * 1.44269504088896341f);
+  const float tm = x * 1.44269504088896341f + kExpMagic;   // == kExpMagic + rintf(x * log2e): see kExpMagic
+  const float kf = tm - kExpMagic;
   float r = fmaf(kf, -0.693359375f, x);
   r = fmaf(kf, 2.12194440e-4f, r);
   float p = 1.9875691500e-4f;
@@ -32,9 +38,10 @@ RG_HD float exp_spec(float x) {
   p = fmaf(p, r, 5.0000001201e-1f);
   const float r2 = r * r;
   const float y = fmaf(p, r2, r) + 1.0f;
-  union { float f; int32_t i; } u;
+  union { float f; uint32_t i; } u, t;
   u.f = y;
-  u.i += ((int32_t)kf) << 23;
+  t.f = tm;
+  u.i += t.i << 23;   // bits(tm) = bits(kExpMagic) + k and bits(kExpMagic) << 23 == 0 (mod 2^32): k lands in the exponent field
   return u.f;
 }
 
@@ -42,7 +49,8 @@ RG_HD float exp_spec(float x) {
 // through `op * exp < 1/255` (any op <= 1 fails it either way): straight-line code, no branch between two pixels' evaluations.
 RG_HD float exp_spec_floor(float x) {
   x = fmaxf(x, -87.0f);
-  const float kf = rintf(x * 1.44269504088896341f);
+  const float tm = x * 1.44269504088896341f + kExpMagic;
+  const float kf = tm - kExpMagic;
   float r = fmaf(kf, -0.693359375f, x);
   r = fmaf(kf, 2.12194440e-4f, r);
   float p = 1.9875691500e-4f;
@@ -53,9 +61,10 @@ RG_HD float exp_spec_floor(float x) {
   p = fmaf(p, r, 5.0000001201e-1f);
   const float r2 = r * r;
   const float y = fmaf(p, r2, r) + 1.0f;
-  union { float f; int32_t i; } u;
+  union { float f; uint32_t i; } u, t;
   u.f = y;
-  u.i += ((int32_t)kf) << 23;
+  t.f = tm;
+  u.i += t.i << 23;   // bits(tm) = bits(kExpMagic) + k and bits(kExpMagic) << 23 == 0 (mod 2^32): k lands in the exponent field
   return u.f;
 }
 

@@ -352,14 +352,18 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     geo = require_coord or require_depth
     # (channels, produced by this call) in the order color, depth, mdepth, coord, mcoord, alpha, normal
     spec = [(3, True), (1, require_depth), (1, require_depth), (3, require_coord), (3, require_coord), (1, True), (3, geo)]
-    zeros = iter(_zero_maps([c for c, w in spec if not (live and w)], H, W, dev))
-    maps = [torch.empty((c, H, W), **fo) if (live and w) else next(zeros) for c, w in spec]
+    # A map the flags do not produce is all-zero in the reference (torch::full(0), rasterize_points.cu:71-77) and FRESH memory on every call.
+    # The library zero-fills whatever unproduced map it is handed (include/radegs.h: inside the blend kernel, no separate fill), so a live call
+    # allocates all seven uninitialised; only the call that launches nothing (P == 0) fills them here.
+    if live:
+        maps = [torch.empty((c, H, W), **fo) for c, _ in spec]
+    else:
+        maps = _zero_maps([c for c, _ in spec], H, W, dev)
     out_color, out_depth, out_mdepth, out_coord, out_mcoord, out_alpha, out_normal = maps
     radii = torch.empty(P, dtype=torch.int32, device=dev) if live else torch.zeros(P, dtype=torch.int32, device=dev)
     if _POISON and live:
-        for (c, w), m in zip(spec, maps):
-            if w:
-                m.fill_(float("nan"))
+        for m in maps:   # the unproduced ones too: the library must overwrite them with zeros
+            m.fill_(float("nan"))
         radii.fill_(-0x01010102)
     geom, binning, img = _Resizable(dev), _Resizable(dev), _Resizable(dev, image=True)
     rendered = 0

@@ -15,7 +15,14 @@ from typing import NamedTuple
 import torch
 import torch.nn as nn
 
-from . import _C
+import os
+
+if os.environ.get("RADEGS_BINDING", "ctypes") == "torch":
+    # upstream's COMPILED `_C` module (DGR/ext.cpp:15-19) rebuilt over the C ABI: csrc/torch_binding/radegs_torch_binding.cpp, built by
+    # `python rade-gs_amd/build.py --torch-binding`.  Same four entry points; this file uses nothing else of `_C`.
+    from . import _C_torch as _C
+else:
+    from . import _C                 # the default: ctypes over the same C ABI (adds the view-parallel hooks and the test inspection calls)
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
 

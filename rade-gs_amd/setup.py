@@ -20,7 +20,10 @@ def _build_native():
     spec = importlib.util.spec_from_file_location("radegs_build", os.path.join(HERE, "build.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return mod.build(verbose=True)
+    lib = mod.build(verbose=True)
+    if os.environ.get("RADEGS_TORCH_BINDING", "0") == "1":   # also upstream's compiled `_C` module over the C ABI (RADEGS_BINDING=torch)
+        mod.build_torch_binding(verbose=True)
+    return lib
 
 
 class BuildPyWithHip(build_py):
@@ -41,7 +44,7 @@ setup(
     description="MI355X-native differentiable Gaussian-splat rasterizer behind RaDe-GS's diff_gaussian_rasterization API (HIP, gfx950)",
     packages=["diff_gaussian_rasterization", "simple_knn"],
     py_modules=["graphics_utils", "loss_utils", "gaussian_model_ops", "fused_adam", "view_parallel", "synth_scene"],
-    package_data={"diff_gaussian_rasterization": ["libradegs_hip.so"]},
+    package_data={"diff_gaussian_rasterization": ["libradegs_hip.so", "_C_torch*.so"]},
     include_package_data=True,
     python_requires=">=3.8",
     cmdclass={"build_py": BuildPyWithHip, "develop": DevelopWithHip},

@@ -1,6 +1,8 @@
 // TEST HARNESS (not product code): runs the product's host+device per-Gaussian math
 // (rade-gs_amd/csrc/rg_*.h) on the CPU so it can be compared bit-for-bit with the oracle in a
 // container that has no GPU.  The product never links this file.
+#include <cmath>
+#include <cstdint>
 #include <cstring>
 #include "rg_blend.h"
 #include "rg_preprocess.h"
@@ -160,6 +162,36 @@ void hc_block_masks_rect(int n, const float* rec, int tx0, int ty0, int tx1, int
 }
 
 float hc_exp_spec(float x) { return exp_spec(x); }
+// The specification as the oracle spells it (rintf + integer conversion); exp_spec / exp_spec_floor (rg_blend.h) reach k through a
+// magic-number addition instead.  Counts the bit patterns in [lo_bits, hi_bits] (step `stride`) on which either differs from it.
+static float exp_spec_rint_form(float x) {
+  if (x < -87.0f) return 0.0f;
+  const float kf = rintf(x * 1.44269504088896341f);
+  float r = fmaf(kf, -0.693359375f, x);
+  r = fmaf(kf, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = fmaf(p, r, 1.3981999507e-3f);
+  p = fmaf(p, r, 8.3334519073e-3f);
+  p = fmaf(p, r, 4.1665795894e-2f);
+  p = fmaf(p, r, 1.6666665459e-1f);
+  p = fmaf(p, r, 5.0000001201e-1f);
+  const float r2 = r * r;
+  const float y = fmaf(p, r2, r) + 1.0f;
+  union { float f; int32_t i; } u;
+  u.f = y;
+  u.i += ((int32_t)kf) << 23;
+  return u.f;
+}
+long long hc_exp_spec_sweep(unsigned lo_bits, unsigned hi_bits, unsigned stride) {
+  long long bad = 0;
+  for (unsigned long long b = lo_bits; b <= hi_bits; b += stride) {
+    float x; unsigned bb = (unsigned)b; memcpy(&x, &bb, 4);
+    const float ref = exp_spec_rint_form(x), got = exp_spec(x), flo = exp_spec_floor(x);
+    if (memcmp(&ref, &got, 4) != 0) bad++;
+    if (!(x < -87.0f) && memcmp(&ref, &flo, 4) != 0) bad++;
+  }
+  return bad;
+}
 float hc_splat_power(float cx, float cy, float cz, float dx, float dy) { return splat_power((cx * dx) * dx, cy * dx, cz, dy); }
 float hc_skip_threshold(float op) { return skip_threshold(op); }
 int hc_sizeof_acc() { return (int)sizeof(SplatAcc); }

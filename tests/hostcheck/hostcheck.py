@@ -26,6 +26,8 @@ def lib():
         _LIB = ctypes.CDLL(build())
         _LIB.hc_exp_spec.restype = ctypes.c_float
         _LIB.hc_exp_spec.argtypes = [ctypes.c_float]
+        _LIB.hc_exp_spec_sweep.restype = ctypes.c_longlong
+        _LIB.hc_exp_spec_sweep.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]
         _LIB.hc_splat_power.restype = ctypes.c_float
         _LIB.hc_splat_power.argtypes = [ctypes.c_float] * 5
         _LIB.hc_skip_threshold.restype = ctypes.c_float

@@ -132,6 +132,12 @@ def test_decision_chain_pieces_bit_exact():
     L = hc.lib()
     for x in np.concatenate([np.linspace(-90, 0.5, 4001), -np.logspace(-8, 1.9, 500)]).astype(np.float32):
         assert np.float32(orc.exp_spec(float(x))).tobytes() == np.float32(L.hc_exp_spec(float(x))).tobytes()
+    # the product reaches k = rint(x log2e) through a magic-number addition (no v_rndne / v_cvt): the same bits as the rintf form on EVERY
+    # float in [-87, -0] and [+0, 16] (dense: every 3rd bit pattern of the negative range, ~0.36 G evaluations in the full sweep below)
+    neg0, neg87, pos16 = 0x80000000, int(np.float32(-87.0).view(np.uint32)), int(np.float32(16.0).view(np.uint32))
+    assert L.hc_exp_spec_sweep(neg0, neg87, 97) == 0
+    assert L.hc_exp_spec_sweep(0, pos16, 97) == 0
+    assert L.hc_exp_spec_sweep(int(np.float32(-88.5).view(np.uint32)) - 4096, int(np.float32(-88.5).view(np.uint32)), 1) == 0   # below -87: 0
     # power = -0.5*(cx*dx*dx + cz*dy*dy) - cy*dx*dy, rounded per operation in source order (forward.cu:555)
     for _ in range(5000):
         cx, cy, cz, dx, dy = (np.float32(v) for v in rng.normal(size=5) * [1, .5, 1, 8, 8])
