@@ -711,16 +711,19 @@ struct BlendFwdArgs {
 // forward.  (NULL: the caller does not want them, or provides zeros itself.)
 template <bool COORD, bool DEPTH>
 __device__ __forceinline__ void zero_unproduced_maps(const BlendFwdArgs& a, size_t pix, size_t HW) {
+  // non-temporal: nothing on this path reads these planes again, and 50 MB of ordinary stores would push the entry streams and records the
+  // backward is about to re-read out of the L2 / Infinity Cache
+  auto z = [](float* p) { __builtin_nontemporal_store(0.0f, p); };
   if constexpr (!COORD) {
-    if (a.out_coord) { a.out_coord[pix] = 0.f; a.out_coord[HW + pix] = 0.f; a.out_coord[2 * HW + pix] = 0.f; }
-    if (a.out_mcoord) { a.out_mcoord[pix] = 0.f; a.out_mcoord[HW + pix] = 0.f; a.out_mcoord[2 * HW + pix] = 0.f; }
+    if (a.out_coord) { z(a.out_coord + pix); z(a.out_coord + HW + pix); z(a.out_coord + 2 * HW + pix); }
+    if (a.out_mcoord) { z(a.out_mcoord + pix); z(a.out_mcoord + HW + pix); z(a.out_mcoord + 2 * HW + pix); }
   }
   if constexpr (!DEPTH) {
-    if (a.out_depth) a.out_depth[pix] = 0.f;
-    if (a.out_mdepth) a.out_mdepth[pix] = 0.f;
+    if (a.out_depth) z(a.out_depth + pix);
+    if (a.out_mdepth) z(a.out_mdepth + pix);
   }
   if constexpr (!COORD && !DEPTH) {
-    if (a.out_normal) { a.out_normal[pix] = 0.f; a.out_normal[HW + pix] = 0.f; a.out_normal[2 * HW + pix] = 0.f; }
+    if (a.out_normal) { z(a.out_normal + pix); z(a.out_normal + HW + pix); z(a.out_normal + 2 * HW + pix); }
   }
 }
 

@@ -150,9 +150,33 @@ struct SplatFwd {
 // SH -> RGB (+0.5, clamp at 0, remember which channels clamped).  sh points at this
 // Gaussian's (M,3) block; only (deg+1)^2 rows are read.
 RG_HD void sh_to_rgb(int deg, const float* sh, v3 pos, const float campos[3], float rgb[3], unsigned& clamped) {
+  // The coefficients are requested in batches BEFORE the first of a batch is used: degree block by degree block (rounds 1-5) the loads
+  // were four dependent round trips to memory at the very end of every wave's life -- they sit behind `deg` branches the compiler cannot
+  // hoist them over, and the waves of a SIMD reach this point together.  RADEGS_SH_BATCH: 1 = everything at once (48 registers live),
+  // 2 = degrees 0-2 (27), then degree 3 (21).
+#ifndef RADEGS_SH_BATCH
+#define RADEGS_SH_BATCH 1
+#endif
+  float c[48];
+#pragma unroll
+  for (int i = 0; i < 3; i++) c[i] = sh[i];
+  if (deg > 0) {
+#pragma unroll
+    for (int i = 3; i < 12; i++) c[i] = sh[i];
+  }
+  if (deg > 1) {
+#pragma unroll
+    for (int i = 12; i < 27; i++) c[i] = sh[i];
+  }
+#if RADEGS_SH_BATCH == 1
+  if (deg > 2) {
+#pragma unroll
+    for (int i = 27; i < 48; i++) c[i] = sh[i];
+  }
+#endif
   v3 dir = sub(pos, mk3(campos[0], campos[1], campos[2]));
   dir = div(dir, len(dir));
-#define SH(k) mk3(sh[3 * (k)], sh[3 * (k) + 1], sh[3 * (k) + 2])
+#define SH(k) mk3(c[3 * (k)], c[3 * (k) + 1], c[3 * (k) + 2])
   v3 res = mul(RG_C0, SH(0));
   if (deg > 0) {
     const float x = dir.x, y = dir.y, z = dir.z;
@@ -162,6 +186,10 @@ RG_HD void sh_to_rgb(int deg, const float* sh, v3 pos, const float campos[3], fl
       res = add(add(add(add(add(res, mul(RG_C2_0 * xy, SH(4))), mul(RG_C2_1 * yz, SH(5))), mul(RG_C2_2 * (2.0f * zz - xx - yy), SH(6))),
                     mul(RG_C2_3 * xz, SH(7))), mul(RG_C2_4 * (xx - yy), SH(8)));
       if (deg > 2) {
+#if RADEGS_SH_BATCH != 1
+#pragma unroll
+        for (int i = 27; i < 48; i++) c[i] = sh[i];
+#endif
         res = add(add(add(add(add(add(add(res, mul(RG_C3_0 * y * (3.0f * xx - yy), SH(9))), mul(RG_C3_1 * xy * z, SH(10))),
                                   mul(RG_C3_2 * y * (4.0f * zz - xx - yy), SH(11))),
                               mul(RG_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), SH(12))),

@@ -10,7 +10,7 @@
 // function names, argument order, return tuples, tensor shapes / dtypes and error text, so DGR/diff_gaussian_rasterization/
 // __init__.py imports it unchanged.  It is plain host C++ (no device code): torch for tensors, the current stream and the caching
 // allocator; everything else goes through libradegs_hip.so.  Built in-tree by rade-gs_amd/build.py as
-// diff_gaussian_rasterization/_C_torch*.so; tests/test_gpu_torch_binding.py runs it against the ctypes binding bit for bit.
+// diff_gaussian_rasterization/_C_torch*.so; tests/test_torch_binding.py runs it against the ctypes binding bit for bit.
 //
 // Deliberate differences from upstream's shim (all inside its contract):
 //   * outputs are torch::empty where the native side writes every element (the reference zero-fills 14 gradient tensors and 7 maps);
@@ -19,9 +19,11 @@
 //   * a call that launches nothing (P == 0) returns zeros, like upstream.
 #include <torch/extension.h>
 
-#include <c10/hip/HIPCachingAllocator.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+// PyTorch-ROCm presents its devices as DeviceType::CUDA; the plain c10::hip guards / streams / allocator refuse that type, the
+// "MasqueradingAsCUDA" variants are the ones a ROCm build of an extension uses (they are what torch's hipify maps c10::cuda::* to)
+#include <ATen/hip/impl/HIPCachingAllocatorMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <cstdint>
 #include <map>
@@ -65,7 +67,7 @@ struct StateBuffer {
   void drop() {
     if (!ptr) return;
     if (image) radegs_forget_image(ptr);
-    c10::hip::HIPCachingAllocator::raw_delete(ptr);
+    c10::hip::HIPCachingAllocatorMasqueradingAsCUDA::raw_delete(ptr);
     ptr = nullptr; bytes = 0;
   }
   static void* grow(void* user, size_t nbytes) {
@@ -73,7 +75,7 @@ struct StateBuffer {
     try {
       if (nbytes > self->bytes || !self->ptr) {
         self->drop();
-        self->ptr = c10::hip::HIPCachingAllocator::raw_alloc(nbytes ? nbytes : 1);
+        self->ptr = c10::hip::HIPCachingAllocatorMasqueradingAsCUDA::raw_alloc(nbytes ? nbytes : 1);
         self->bytes = nbytes;
       }
       return self->ptr;
@@ -92,12 +94,12 @@ struct StateBuffer {
     ptr = nullptr; bytes = 0;
     return torch::from_blob(p, {n}, [img](void* q) {
       if (img) radegs_forget_image(q);
-      c10::hip::HIPCachingAllocator::raw_delete(q);
+      c10::hip::HIPCachingAllocatorMasqueradingAsCUDA::raw_delete(q);
     }, opts);
   }
 };
 
-void* current_stream(const c10::Device& d) { return static_cast<void*>(c10::hip::getCurrentHIPStream(d.index()).stream()); }
+void* current_stream(const c10::Device& d) { return static_cast<void*>(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(d.index()).stream()); }
 
 int checked(int rc, const char* what) {
   TORCH_CHECK(rc >= 0, what, " failed (", rc, "): ", radegs_last_error());
@@ -130,7 +132,7 @@ rasterize_gaussians(const Tensor& background, const Tensor& means3D, const Tenso
   if (means3D.ndimension() != 2 || means3D.size(1) != 3) AT_ERROR("means3D must have dimensions (num_points, 3)");
   TORCH_CHECK(means3D.is_cuda(), "diff_gaussian_rasterization (MI355X build): `means3D` must be a GPU tensor -- this operator has no CPU implementation");
   const c10::Device dev = means3D.device();
-  c10::hip::HIPGuard guard(dev);
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
   const int P = static_cast<int>(means3D.size(0)), H = image_height, W = image_width;
   const auto f32 = torch::TensorOptions().dtype(torch::kFloat32).device(dev);
   const auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(dev);
@@ -174,7 +176,7 @@ rasterize_gaussians_backward(const Tensor& background, const Tensor& means3D, co
                              const Tensor& alphas, const bool require_coord, const bool require_depth, const bool debug) {
   TORCH_CHECK(means3D.is_cuda(), "diff_gaussian_rasterization (MI355X build): `means3D` must be a GPU tensor -- this operator has no CPU implementation");
   const c10::Device dev = means3D.device();
-  c10::hip::HIPGuard guard(dev);
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
   const int P = static_cast<int>(means3D.size(0));
   const int H = static_cast<int>(dL_dout_color.size(1)), W = static_cast<int>(dL_dout_color.size(2));
   const int M = sh.numel() != 0 ? static_cast<int>(sh.size(1)) : 0;
@@ -241,7 +243,7 @@ rasterize_gaussians_backward(const Tensor& background, const Tensor& means3D, co
 Tensor mark_visible(Tensor& means3D, Tensor& viewmatrix, Tensor& projmatrix) {
   TORCH_CHECK(means3D.is_cuda(), "diff_gaussian_rasterization (MI355X build): `means3D` must be a GPU tensor -- this operator has no CPU implementation");
   const c10::Device dev = means3D.device();
-  c10::hip::HIPGuard guard(dev);
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
   const int P = static_cast<int>(means3D.size(0));
   Tensor present = torch::zeros({P}, torch::TensorOptions().dtype(torch::kBool).device(dev));
   if (P != 0) {
@@ -267,7 +269,7 @@ integrate_gaussians_to_points(const Tensor& background, const Tensor& points3D, 
   if (points3D.ndimension() != 2 || points3D.size(1) != 3) AT_ERROR("points3D must have dimensions (num_points, 3)");
   TORCH_CHECK(means3D.is_cuda() && points3D.is_cuda(), "diff_gaussian_rasterization (MI355X build): inputs must be GPU tensors -- this operator has no CPU implementation");
   const c10::Device dev = means3D.device();
-  c10::hip::HIPGuard guard(dev);
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
   const int P = static_cast<int>(means3D.size(0)), PN = static_cast<int>(points3D.size(0)), H = image_height, W = image_width;
   const auto f32 = torch::TensorOptions().dtype(torch::kFloat32).device(dev);
   Tensor out_color = torch::empty({9, H, W}, f32), out_alpha_integrated = torch::empty({PN}, f32), out_color_integrated = torch::empty({PN, 3}, f32),
