@@ -16,7 +16,7 @@ from collections import Counter
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "rade-gs_amd", "diff_gaussian_rasterization", "libradegs_hip.so")
+LIB = os.environ.get("RADEGS_LIB") or os.path.join(ROOT, "rade-gs_amd", "diff_gaussian_rasterization", "libradegs_hip.so")
 
 QUARTER = ("v_exp_f32", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_log_f32", "v_sin_f32", "v_cos_f32", "v_permlane", "v_rcp_iflag", "v_div_fmas",
            "v_div_scale", "v_div_fixup", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_hi_i32", "v_mad_u64_u32", "v_mad_i64_i32")

@@ -69,7 +69,8 @@ BUDGET = [
     (("blend_bwd_streams_kernelILb0ELb0EE",), 5, 0, 6826),
     (("blend_bwd_streams_kernelILb1ELb1EE",), 4, 0, 10240),     # coord-map modes: two 64-byte lines per (block, entry), one atomic instruction each
     (("blend_bwd_streams_kernelILb1ELb0EE",), 4, 0, 10240),
-    (("preprocess_fwd_kernelILb0E",), 6, 0, 0),
+    (("preprocess_fwd_kernelILb0E",), 5, 0, 0),                      # 5 since round 6: all 48 SH coefficients in flight at once (one round trip
+                                                                     # instead of four; same-box A/B against two batches at 6 waves: 0.094 | 0.096 ms)
     (("preprocess_bwd_kernel",), 3, 16, 0),                          # dynamic LDS: the SH slab
     (("block_lists_kernelILb0E",), 8, 0, 256),
     (("block_counts_kernelILb0E",), 8, 0, 512),
