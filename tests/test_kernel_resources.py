@@ -62,11 +62,11 @@ def find(kernels, *parts):
 BUDGET = [
     (("blend_fwd_streams_kernelILb0ELb1EE",), 7, 0, 4608),      # C2 / C3 forward blend (depth mode)
     (("blend_fwd_streams_kernelILb0ELb0EE",), 7, 0, 4608),
-    (("blend_fwd_streams_kernelILb1ELb1EE",), 4, 32, 8192),     # coord-map modes (forcing 5 / 6 waves spills); 32 B: one
-                                                                 # staged record row goes through scratch once per round of 16 entries
-    # the stream backward: staged records + 2.3 KB of row-reduction scratch; 6 826 B = 160 KB / 24 is what lets a CU hold 6 waves per SIMD
-    (("blend_bwd_streams_kernelILb0ELb1EE",), 5, 0, 6826),      # the dominant kernel (5 waves: measured faster than 6 with a spill)
-    (("blend_bwd_streams_kernelILb0ELb0EE",), 5, 0, 6826),
+    (("blend_fwd_streams_kernelILb1ELb1EE",), 4, 0, 8192),      # coord-map modes: no scratch since the camera-plane record is loaded unconditionally
+    (("blend_fwd_streams_kernelILb1ELb0EE",), 5, 0, 8192),      # and zeroed by selects (round 6; rounds 3-5: 4 waves + 32 B of scratch in both)
+    # the stream backward: staged records + ids + positions + 2.3 KB of row-reduction scratch; 20 waves per CU (5 per SIMD) x 6 976 B = 139 KB
+    (("blend_bwd_streams_kernelILb0ELb1EE",), 5, 0, 6976),      # the dominant kernel (5 waves: measured faster than 6 with a spill)
+    (("blend_bwd_streams_kernelILb0ELb0EE",), 5, 0, 6976),
     (("blend_bwd_streams_kernelILb1ELb1EE",), 4, 0, 10240),     # coord-map modes: two 64-byte lines per (block, entry), one atomic instruction each
     (("blend_bwd_streams_kernelILb1ELb0EE",), 4, 0, 10240),
     (("preprocess_fwd_kernelILb0E",), 5, 0, 0),                      # 5 since round 6: all 48 SH coefficients in flight at once (one round trip
