@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--settle-ms", type=float, default=40.0,
+                    help="untimed repetitions of the step between the warm-up and the timed region until this much time has gone by, so that the GPU "
+                         "has reached its sustained clock when timing starts (0 = none; reported on the line as `settle`)")
     ap.add_argument("--config", default="C2", help="BASELINE.json config (C1..C5); the headline metric is quoted on C2")
     ap.add_argument("--points", type=int, default=0, help="override the number of Gaussians (debug only)")
     ap.add_argument("--mu-px", type=float, default=0.0, help="override the median splat size in pixels (debug only)")
@@ -178,6 +181,19 @@ def main():
     # Warm-up: the per-stage breakdown (`stages_ms`) is measured HERE, with an event pair around every stage.  Each recorded
     # stage boundary costs ~10 us of stream bubble (10 stages = ~0.1 ms per step), so the timed steps below record events
     # around the dominant kernel only -- the one the roofline object reports, live, inside the timed region.
+    # Python's cyclic collector is emptied HERE -- before the warm-up, not between the warm-up and the timed region -- and held off until
+    # the timed region ends: a generation-2 pass over a torch process's ~1 M objects is a 5-30 ms host stall (seen as ONE step of 6 / 30 /
+    # 31 ms on C2 / C4 / C5 lines of round 6 whose median span was 1.41 / 4.09 / 7.71).  Emptying it right before the timed region (the
+    # round's first version) idled the GPU for that long after its warm-up: the clocks fell back and the first six timed steps ran 10-20 %
+    # slow (`step_gpu_span_ms.in_step_order`: 1.50 1.52 1.59 1.49 1.46 1.43 1.37 ... 1.30).  Nothing between the warm-up's closing fence and
+    # the first timed step takes longer than a few hundred microseconds now.  No GPU work is skipped or moved by any of this.
+    import gc
+    gc.collect()
+    gc_was_enabled = gc.isenabled()
+    gc.disable()
+    # one event per step boundary on the launch stream (~2 us each, no bubble: nothing waits on them): the spans between them say what a
+    # step costs on the GPU, so that a host stalled by a neighbour (the boxes' hosts are shared) shows up as wall >> median span
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     if args.warmup > 1:  # first call: allocator growth, code-object load -- keep it out of the per-stage averages
         R, radii, _ = step()
         fence()
@@ -191,6 +207,20 @@ def main():
     dom = None
     if args.warmup > 0:
         dom = max(STAGES4, key=lambda k: stages_warm[k][0] / max(stages_warm[k][1], 1))
+    # Clock settling (disclosed on the line as `settle`): after an idle period the GPU reaches its sustained clock only after ~20 ms of
+    # continuous work -- with `--views 1` as with rotating views the first ~15 steps after the warm-up's fence run 10 % slow and decay
+    # smoothly (`step_gpu_span_ms.in_step_order` of a run with --settle-ms 0: 1.42 1.37 1.41 1.38 1.36 ... 1.29), and W = 5 warm-up steps
+    # are 7 ms.  Throughput is a steady-state quantity (a training run is thousands of iterations), so the same step is repeated, untimed,
+    # until `--settle-ms` of GPU work have gone by; the timed K steps follow the usual barrier + synchronize.  Nothing inside the timed
+    # region changes.
+    n_settle = 0
+    if args.settle_ms > 0 and args.warmup > 0:
+        t_s = time.perf_counter()
+        while (time.perf_counter() - t_s) * 1e3 < args.settle_ms and n_settle < 200:
+            for _ in range(4):      # (every forward waits for its own instance count: the host cannot run far ahead of the GPU)
+                R, radii, _ = step()
+            n_settle += 4
+        fence()
     # the dominant kernel is timed live on every 2nd step of the timed region (the event pair around it is a ~12 us stream bubble;
     # every 2nd step of a 9-view rotation still visits every view)
     C.profile_enable(True, only=dom, every=2 if (dom is not None and args.steps >= 8) else 1)   # no warm-up steps: every stage, in the timed region
@@ -198,18 +228,8 @@ def main():
         bucket.collect_timing()      # drop the warm-up steps' exchange timings
     C.binning_stats(reset=True)
     Rs, vis = [], []
-    # one event per step boundary on the launch stream (~2 us each, no bubble: nothing waits on them): the spans between them say what a
-    # step costs on the GPU, so that a host stalled by a neighbour (the boxes' hosts are shared) shows up as wall >> median span
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     torch.cuda.reset_peak_memory_stats(dev)
     mem_before = torch.cuda.memory_allocated(dev)
-    # Python's cyclic collector is emptied before and held off during the timed region: a generation-2 pass over a torch process's ~1 M
-    # objects is a 5-30 ms host stall inside ONE step (seen as step_gpu_span_ms.max of 6 / 30 / 31 ms on C2 / C4 / C5 lines of round 6
-    # whose median span was 1.41 / 4.09 / 7.71).  No GPU work is skipped or moved by this; the collector runs again after the region.
-    import gc
-    gc.collect()
-    gc_was_enabled = gc.isenabled()
-    gc.disable()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -297,7 +317,10 @@ def main():
                               "achieved_GBs_gpu_time": round(ab["total"] / (gpu_ms * 1e-3) / 1e9, 1) if gpu_ms > 0 else 0.0,
                               "achieved_GBs_wall": round(ab["total"] / (ms_per_step * 1e-3) / 1e9, 1),
                               "frac_wall": round(ab["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-            "step_gpu_span_ms": {"median": round(spans[len(spans) // 2], 4), "min": round(spans[0], 4), "max": round(spans[-1], 4),
+            "settle": {"untimed_steps": n_settle, "ms": args.settle_ms,
+                       "note": "untimed repetitions of the step between the W warm-up steps and the timed region, until the GPU has worked for `ms`: "
+                               "its clock settles only after ~20 ms of continuous work (first steps after an idle period run ~10 % slow)"},
+            "step_gpu_span_ms": {"median": round(spans[len(spans) // 2], 4), "min": round(spans[0], 4), "max": round(spans[-1], 4), "mean": round(sum(spans) / len(spans), 4), "in_step_order": [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(args.steps)],
                                  "note": "HIP-event spans between consecutive steps on the launch stream; ms_per_step is the wall clock of the whole region / steps; "
                                          "Python's cyclic GC is collected before and disabled during the timed region (a gen-2 pass is a 5-30 ms host stall)"},
             "device_memory": {"peak_bytes_of_one_step": int(peak_step_bytes),
