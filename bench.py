@@ -16,6 +16,10 @@ others' (what the speculative binning's capacity prediction has to survive; `spe
 often it did not).  For N>1 every rank walks its OWN views of the replicated Gaussians (weak scaling) and the
 step ends with the RCCL exchange of the parameter gradients.  Inputs are resident in HBM before the timed region.
 
+Order of a run: W warm-up steps (per-stage event timing -> `stages_ms`), fence, untimed repetitions of the step for `--settle-ms`
+(default 40 ms; reported as `settle`: the GPU's clock settles only after ~20 ms of continuous work, 0 turns it off), fence
+(barrier + synchronize), EXACTLY K timed steps, fence.  `step_gpu_span_ms` carries every timed step's GPU span in order.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      dominant kernel: algorithmic bytes per launch / its average
                 launch duration, measured with HIP events recorded by the library on the launch stream
