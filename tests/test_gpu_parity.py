@@ -474,6 +474,50 @@ def test_unproduced_maps_are_zero_call_after_call():
             assert not bool(normal.any())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("streams", [0, 1])
+def test_c_abi_zero_fills_the_unproduced_maps_it_is_handed_and_only_those(streams, monkeypatch):
+    """include/radegs.h (round 6): a map the flags do not produce is zero-filled by the forward when its pointer is non-NULL -- every pixel, by
+    the blend kernel of either formulation, also in a ragged image -- and not touched at all when it is NULL.  Through ctypes, past the binding."""
+    import ctypes
+    import diff_gaussian_rasterization._C as C
+    monkeypatch.setenv("RADEGS_STREAMS", str(streams))
+    C.reload_env()
+    dev = torch.device(_dev())
+    s = make_scene(3000, 203, 131, sh_degree=1, mu_px=2.5, seed=91, kernel_size=0.1, require_coord=False, require_depth=False, pose="random")
+    from synth_scene import to_device
+    d = to_device(s, dev)
+    P, H, W = 3000, s.H, s.W
+    L = C.library()
+
+    def run(hand_over):
+        f = dict(dtype=torch.float32, device=dev)
+        color, alpha = torch.empty((3, H, W), **f), torch.empty((1, H, W), **f)
+        extra = {k: torch.full((c, H, W), float("nan"), **f) for k, c in (("coord", 3), ("mcoord", 3), ("depth", 1), ("mdepth", 1), ("normal", 3))}
+        radii = torch.empty(P, dtype=torch.int32, device=dev)
+        geom, binning, img = C._Resizable(dev), C._Resizable(dev), C._Resizable(dev, image=True)
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+        opt = (lambda k: ptr(extra[k])) if hand_over else (lambda k: None)
+        a = C.RadegsFwdArgs(P, s.sh_degree, int(d.shs.size(1)), W, H, ptr(d.bg), ptr(d.means3D), ptr(d.shs), None, ptr(d.opacities), ptr(d.scales),
+                            ptr(d.rotations), None, ptr(d.viewmatrix), ptr(d.projmatrix), ptr(d.campos), 1.0, float(s.tanfovx), float(s.tanfovy),
+                            float(s.kernel_size), 0, 0, 0, 0, ptr(color), opt("coord"), opt("mcoord"), opt("depth"), opt("mdepth"), ptr(alpha),
+                            opt("normal"), ptr(radii))
+        rc = L.radegs_forward(ctypes.byref(a), geom.cb, None, binning.cb, None, img.cb, None, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        torch.cuda.synchronize(dev)
+        for r in (geom, binning, img):
+            r.release()
+        assert rc > 0, L.radegs_last_error()
+        return color, alpha, extra
+    color_a, alpha_a, ex_a = run(True)
+    for k, t in ex_a.items():
+        assert not bool(torch.isnan(t).any()) and not bool(t.any()), k          # handed over: all zeros, no pixel left out
+    color_b, alpha_b, ex_b = run(False)
+    for k, t in ex_b.items():
+        assert bool(torch.isnan(t).all()), k                                     # NULL: never touched
+    assert torch.equal(color_a, color_b) and torch.equal(alpha_a, alpha_b)
+    assert C.last_forward_used_streams() is bool(streams)
+
+
 def test_stream_byte_budget_falls_back_to_the_tile_wide_kernels(monkeypatch):
     """RADEGS_STREAMS_MAX_MB: above the budget the launcher does not ask for entry-stream storage;
     the tile-wide kernels then run on the plain image state -- same results."""

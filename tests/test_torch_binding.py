@@ -137,6 +137,33 @@ def test_compiled_module_equals_the_ctypes_binding(coord, depth, precomp):
 
 
 @pytest.mark.gpu
+def test_compiled_module_runs_on_the_current_stream():
+    """The module queues on torch's CURRENT stream of the inputs' device (c10::hip::getCurrentHIPStreamMasqueradingAsCUDA), as upstream's
+    kernels do: a forward + backward issued inside `torch.cuda.stream(side)` is ordered with the side stream's other work and equals the
+    default-stream result."""
+    from gpu_util import HipRun
+    T = _binding()
+    dev = "cuda:0"
+    s = make_scene(4000, 224, 160, sh_degree=1, mu_px=2.5, seed=412, kernel_size=0.0, require_coord=False, require_depth=True, pose="random")
+    h = HipRun(s, dev)
+    args = _native_args(h)
+    ref = T.rasterize_gaussians(*args)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        scaled = h.opacities.detach() * 1.0          # produced ON the side stream: the forward must be queued behind it
+        a2 = list(args); a2[3] = scaled
+        out = T.rasterize_gaussians(*a2)
+        doubled = out[1] * 2.0
+    side.synchronize()
+    assert out[0] == ref[0]
+    for k in range(1, 9):
+        assert torch.equal(out[k], ref[k]), k
+    assert torch.equal(doubled, ref[1] * 2.0)
+
+
+@pytest.mark.gpu
 def test_mark_visible_and_integrate_through_the_compiled_module():
     from gpu_util import HipRun
     import diff_gaussian_rasterization._C as C
