@@ -109,8 +109,14 @@ int checked(int rc, const char* what) {
 // The accumulation scratch of the backward: one all-zero buffer per (device, stream), handed back all-zero by every successful
 // call (RadegsBwdArgs.acc_reuse) -- up to 256 MB; larger ones are allocated per call and filled by the library.
 constexpr size_t kAccReuseMaxBytes = size_t(256) << 20;
+// The mutex is held for the whole of a backward that uses a cached scratch: two host threads queueing backwards on ONE stream would
+// otherwise interleave their kernels over the same buffer (each call's kernels must run back to back: the second one clears what the first
+// accumulated).  The map is leaked on purpose: tensors destroyed during static destruction would outlive the HIP context.
 std::mutex g_acc_mutex;
-std::map<std::pair<int, void*>, Tensor> g_acc_scratch;
+std::map<std::pair<int, void*>, Tensor>& acc_scratch_map() {
+  static auto* m = new std::map<std::pair<int, void*>, Tensor>();
+  return *m;
+}
 
 struct AccRequest { Tensor t; bool failed = false; };
 void* acc_fixed(void* user, size_t nbytes) {
@@ -199,13 +205,15 @@ rasterize_gaussians_backward(const Tensor& background, const Tensor& means3D, co
     const bool reuse = abytes <= kAccReuseMaxBytes;
     AccRequest acc;
     StateBuffer acc_fresh(dev, false);
+    std::unique_lock<std::mutex> scratch_lock(g_acc_mutex, std::defer_lock);
     if (reuse) {
-      std::lock_guard<std::mutex> lock(g_acc_mutex);
-      auto it = g_acc_scratch.find(key);
-      if (it == g_acc_scratch.end() || static_cast<size_t>(it->second.numel()) < abytes) {
-        if (g_acc_scratch.size() >= 8) g_acc_scratch.clear();
-        g_acc_scratch[key] = torch::zeros({static_cast<int64_t>(abytes ? abytes : 1)}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
-        it = g_acc_scratch.find(key);
+      scratch_lock.lock();
+      auto& cache = acc_scratch_map();
+      auto it = cache.find(key);
+      if (it == cache.end() || static_cast<size_t>(it->second.numel()) < abytes) {
+        if (cache.size() >= 8) cache.clear();
+        cache[key] = torch::zeros({static_cast<int64_t>(abytes ? abytes : 1)}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+        it = cache.find(key);
       }
       acc.t = it->second;
     }
@@ -226,10 +234,8 @@ rasterize_gaussians_backward(const Tensor& background, const Tensor& means3D, co
     a.require_coord = require_coord ? 1 : 0; a.require_depth = require_depth ? 1 : 0; a.debug = debug ? 1 : 0;
     a.acc_reuse = reuse ? 1 : 0;
     const int rc = reuse ? radegs_backward(&a, acc_fixed, &acc, stream) : radegs_backward(&a, StateBuffer::grow, &acc_fresh, stream);
-    if (reuse && (rc != 0 || acc.failed)) {   // the scratch is in an unknown state: the next call starts from a fresh one
-      std::lock_guard<std::mutex> lock(g_acc_mutex);
-      g_acc_scratch.erase(key);
-    }
+    if (reuse && (rc != 0 || acc.failed)) acc_scratch_map().erase(key);   // unknown state: the next call starts from a fresh one
+    if (reuse) scratch_lock.unlock();
     checked(rc, "radegs_backward");
     if (!sc.p) {   // precomputed covariance: scale / rotation gradients are identically zero
       dL_dscales.zero_();

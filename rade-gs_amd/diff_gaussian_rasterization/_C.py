@@ -298,6 +298,9 @@ class _Fixed:
 
 
 _ACC_SCRATCH = {}   # (device index, stream handle) -> all-zero uint8 tensor, kept zero by the backward itself (RadegsBwdArgs.acc_reuse)
+# held for the whole of a backward that uses a cached scratch: ctypes drops the GIL during the native call, and two host threads queueing
+# backwards on ONE stream would otherwise interleave their kernels over the same buffer
+_ACC_LOCK = threading.Lock()
 
 
 def _acc_scratch(key, nbytes, device):
@@ -476,11 +479,17 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                           ctypes.cast(ready_cb, ctypes.c_void_p) if ready_cb is not None else None, None,
                           nchunks, ctypes.cast(chunks_cb, ctypes.c_void_p) if chunks_cb is not None else None, None,
                           int(bool(KEEP_ACC)), int(acc_cached is not None))
-        with torch.cuda.device(dev):
-            rc = L.radegs_backward(ctypes.byref(a), acc.cb, None, _stream(dev))
-        acc.release()
-        if acc_cached is not None and (rc != 0 or acc.error is not None or ready_err):
-            _ACC_SCRATCH.pop(akey, None)   # the scratch is in an unknown state: the next call starts from a fresh one
+        if acc_cached is not None:
+            _ACC_LOCK.acquire()
+        try:
+            with torch.cuda.device(dev):
+                rc = L.radegs_backward(ctypes.byref(a), acc.cb, None, _stream(dev))
+            acc.release()
+            if acc_cached is not None and (rc != 0 or acc.error is not None or ready_err):
+                _ACC_SCRATCH.pop(akey, None)   # the scratch is in an unknown state: the next call starts from a fresh one
+        finally:
+            if acc_cached is not None:
+                _ACC_LOCK.release()
         if acc.error is not None:
             raise acc.error
         if ready_err:
