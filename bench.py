@@ -219,11 +219,21 @@ def main():
     # region changes.
     n_settle = 0
     if args.settle_ms > 0 and args.warmup > 0:
+        # how many: from the duration of the first four, the SAME count on every rank (under the launcher a step ends with a collective:
+        # ranks that counted by their own clocks would issue different numbers of them and hang)
         t_s = time.perf_counter()
-        while (time.perf_counter() - t_s) * 1e3 < args.settle_ms and n_settle < 200:
-            for _ in range(4):      # (every forward waits for its own instance count: the host cannot run far ahead of the GPU)
-                R, radii, _ = step()
-            n_settle += 4
+        for _ in range(4):
+            R, radii, _ = step()
+        torch.cuda.synchronize(dev)
+        est_ms = (time.perf_counter() - t_s) * 1e3 / 4
+        if launched:
+            t_est = torch.tensor([est_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(t_est, op=dist.ReduceOp.MAX)
+            est_ms = float(t_est.item())
+        n_settle = min(200, max(4, -(-int(args.settle_ms * 1000) // max(int(est_ms * 1000), 1))))
+        n_settle = (n_settle + 3) // 4 * 4
+        for _ in range(n_settle - 4):
+            R, radii, _ = step()
         fence()
     # the dominant kernel is timed live on every 2nd step of the timed region (the event pair around it is a ~12 us stream bubble;
     # every 2nd step of a 9-view rotation still visits every view)
