@@ -47,6 +47,11 @@ CONFIGS = {
     # footprint distribution (log-normal sigma 1.3 instead of 0.6, plus 2 % of splats of 64 px and more) and Gaussians clustered on 200
     # blobs, so that tile-list lengths span more than an order of magnitude.  What the per-launch choice between the two blend
     # formulations has to survive (bench.py --config C2H; profiles/r05_C2H_*).
+    # not a BASELINE config: VERDICT r5's "C2M" -- C2 plus 0.5 % screen-filling splats (200 .. 600 px) confined to the left third of the
+    # image: two thirds of the tiles look like C2 (small splats: the entry streams' case), one third like C5 (the tile-wide kernels' case).
+    # What a per-tile-band choice of blend formulation would have to beat (bench.py --config C2M).
+    "C2M": dict(P=1_000_000, W=1920, H=1080, sh_degree=3, mu_px=1.5, require_coord=False, require_depth=True, seed=12,
+                big_frac=0.005, big_px=200.0, big_band=(-1.0, -1.0 / 3.0)),
     "C2H": dict(P=1_000_000, W=1920, H=1080, sh_degree=3, mu_px=1.0, require_coord=False, require_depth=True, seed=11,
                 sigma_ln=1.3, big_frac=0.02, big_px=64.0, clusters=200),
 }
@@ -99,7 +104,7 @@ def _t(a):
 
 def make_scene(P, W, H, sh_degree=3, mu_px=1.5, seed=0, kernel_size=0.0, require_coord=False, require_depth=True,
                low_opacity=False, pose="identity", fovx_deg=60.0, bg=(0.0, 0.0, 0.0), near_cull_frac=0.02,
-               filter3d=True, sigma_ln=0.6, big_frac=0.0, big_px=64.0, clusters=0) -> Scene:
+               filter3d=True, sigma_ln=0.6, big_frac=0.0, big_px=64.0, clusters=0, big_band=None) -> Scene:
     """sigma_ln: width of the log-normal footprint distribution; big_frac / big_px: that share of the splats gets a footprint of
     big_px .. 3 big_px pixels (6 sigma) instead; clusters > 0: the Gaussians sit on that many blobs (centres uniform in the frustum, blob radius
     3 .. 25 % of the blob's depth, blob populations log-normal) instead of filling the frustum uniformly."""
@@ -153,6 +158,10 @@ def make_scene(P, W, H, sh_degree=3, mu_px=1.5, seed=0, kernel_size=0.0, require
     if big_frac > 0:
         big = gen.rand(P) < big_frac
         sigma_px = np.where(big, big_px / 6.0 * np.exp(U(P, 0.0, math.log(3.0))), sigma_px)   # footprint ~ 6 sigma: big_px .. 3 big_px
+        if big_band is not None:   # the big splats' centres lie in this band of normalised image x (-1 .. 1); drawn AFTER everything above:
+            xb = zz * tanfovx * U(P, big_band[0], big_band[1])   # configs without a band keep their streams
+            cam_pts[:, 0] = np.where(big & (z > 0.2), xb, cam_pts[:, 0])
+            means3D = (cam_pts - T) @ Rw2c
     aniso = np.exp(0.5 * gen.randn(P, 3))
     scales = (zz * sigma_px / focal_x)[:, None] * aniso
     if low_opacity:

@@ -259,6 +259,17 @@ def test_trained_scene_shape_both_paths(streams, monkeypatch):
     check_backward(s, o, seed=11)
 
 
+@pytest.mark.parametrize("streams", [0, 1])
+def test_mixed_scene_shape_both_paths(streams, monkeypatch):
+    """VERDICT r5's "C2M" (synth_scene CONFIGS["C2M"]) at a reduced size: C2's small splats plus 0.5 % splats of 50-150 px confined to the left
+    third of the image -- two thirds of the tiles the entry streams' case, one third the tile-wide kernels' -- through either formulation."""
+    monkeypatch.setenv("RADEGS_STREAMS", str(streams))
+    s = make_scene(40_000, 480, 270, sh_degree=3, mu_px=1.5, seed=12, kernel_size=0.0, require_coord=False, require_depth=True,
+                   big_frac=0.005, big_px=50.0, big_band=(-1.0, -1.0 / 3.0))
+    o, _ = check_forward(s)
+    check_backward(s, o, seed=12)
+
+
 def test_entry_streams_heavy_overdraw_termination_and_ragged_image(monkeypatch):
     """Forced entry streams on big splats: lists of hundreds of entries per block, rows of pixels that terminate early (their
     block stops consuming its list) next to rows that do not, partial rounds, tail tiles of a ragged image."""
