@@ -114,13 +114,16 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const K* __restri
   if (n_dev) n = min(n, *n_dev);
   __shared__ uint32_t digit_base[BINS];       // global offset of this block's first item of each digit
   __shared__ uint32_t local_start[BINS];      // position of each digit's first item in the block-local sorted order
-  __shared__ uint32_t wave_cnt[4][BINS];      // histogram of each wave's run, then running rank counters
+  // 16-bit counters (a wave's run has at most 64 * ITEMS = 2 048 items, a block 8 192): with ITEMS = 32 and 16-bit keys the workgroup's LDS
+  // is 53.3 KB instead of 55.3 -- THREE workgroups per CU (160 KB) instead of two (round 6; C5's 50 M-instance tile sort)
+  __shared__ uint16_t wave_cnt[4][BINS];      // histogram of each wave's run, then running rank counters
   __shared__ uint32_t scan_tmp[4];
   __shared__ K lds_k[BLOCK_ITEMS];            // the block's items reordered by digit (stable), so that the global
   __shared__ uint32_t lds_v[BLOCK_ITEMS];     // writes below go out in contiguous per-digit runs
   // ITEMS = 32 (tens of millions of items, C5): 2 x 32 KB + 6 KB of counters = 70 KB of LDS per workgroup -- above the 64 KB of every
   // AMD architecture before gfx950 (160 KB per CU).  This library is built for gfx950 only (build.py: ARCH).
   static_assert(2 * BLOCK_ITEMS * sizeof(uint32_t) + 8 * BINS * sizeof(uint32_t) <= 160 * 1024, "scatter_kernel: LDS footprint exceeds gfx950's 160 KB");
+  static_assert(64 * ITEMS < 65536 && kSortThreads * ITEMS < 65536, "scatter_kernel: 16-bit counters");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   {   // exclusive scan of the digit totals (thread t owns digits PER t .. PER t + PER - 1) + this block's offset inside each digit
     uint32_t tot[PER], sum = 0;
@@ -156,7 +159,10 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const K* __restri
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
     const uint32_t i = run0 + r * 64 + lane;
-    if (i < n) atomicAdd(&wave_cnt[wave][((rk[r] - key_base) >> shift) & mask], 1u);
+    if (i < n) {   // (LDS atomics are 32-bit: the increment goes to the digit's half of its word; a half never carries -- counts <= 2 048)
+      const uint32_t d = ((rk[r] - key_base) >> shift) & mask;
+      atomicAdd(reinterpret_cast<uint32_t*>(&wave_cnt[wave][d & ~1u]), 1u << (16u * (d & 1u)));
+    }
   }
   __syncthreads();
   // per digit: the 4 wave counts become exclusive prefixes (wave w starts after waves < w); block total per digit
@@ -168,7 +174,7 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const K* __restri
 #pragma unroll
       for (int w = 0; w < 4; w++) {
         const uint32_t c = wave_cnt[w][PER * tid + q];
-        wave_cnt[w][PER * tid + q] = block_count;
+        wave_cnt[w][PER * tid + q] = (uint16_t)block_count;
         block_count += c;
       }
       bc[q] = block_count;
@@ -202,7 +208,7 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const K* __restri
     if (valid) before = wave_cnt[wave][digit];          // items of this digit earlier in the block order
     // the first lane of every peer group advances the running counter (one writer per digit: no atomic needed)
     __builtin_amdgcn_wave_barrier();
-    if (valid && lower == 0) wave_cnt[wave][digit] = before + count_in_step;
+    if (valid && lower == 0) wave_cnt[wave][digit] = (uint16_t)(before + count_in_step);
     __builtin_amdgcn_wave_barrier();
     if (valid) {
       const uint32_t pos = local_start[digit] + before + rank_in_step;
