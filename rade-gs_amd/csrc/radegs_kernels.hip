@@ -274,18 +274,34 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32
 }
 
 // key_mask: the bits of a key that are the tile id (32-bit keys of a scene of 2^24 Gaussians and more carry the block mask above them)
+// One 16-byte load of consecutive keys per thread (8 of the 16-bit ones) and the key before them (rounds 1-5: one key and its predecessor
+// per thread, two 2-byte loads: 107 us for C5's 50 M keys); `cap` = items the buffer holds (a vector that would reach past it goes key by key).
+constexpr int kRangeThreads = 256;
 template <class K>
-__global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const K* keys, uint2* ranges, const uint32_t* L_dev, uint32_t key_mask) {
+__global__ void __launch_bounds__(kRangeThreads) tile_ranges_kernel(int L, const K* keys, uint2* ranges, const uint32_t* L_dev, uint32_t key_mask, int cap) {
+  constexpr int V = 16 / (int)sizeof(K);
   if (L_dev) L = (int)min((uint32_t)L, *L_dev);  // capacity launch, see emit_instances_kernel
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= L) return;
-  const uint32_t cur = (uint32_t)keys[i] & key_mask;
-  if (i == 0) ranges[cur].x = 0;
-  else {
-    const uint32_t prev = (uint32_t)keys[i - 1] & key_mask;
-    if (cur != prev) { ranges[prev].y = i; ranges[cur].x = i; }
+  const long long base = ((long long)blockIdx.x * kRangeThreads + threadIdx.x) * V;
+  if (base >= L) return;
+  K v[V];
+  if (base + V <= cap) {
+    const uint4 w = *reinterpret_cast<const uint4*>(keys + base);
+    __builtin_memcpy(v, &w, 16);
+  } else {
+#pragma unroll
+    for (int k = 0; k < V; k++) v[k] = base + k < cap ? keys[base + k] : (K)0;
   }
-  if (i == L - 1) ranges[cur].y = L;
+  uint32_t prev = base > 0 ? ((uint32_t)keys[base - 1] & key_mask) : 0u;
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    const long long i = base + k;
+    if (i >= L) break;
+    const uint32_t cur = (uint32_t)v[k] & key_mask;
+    if (i == 0) ranges[cur].x = 0;
+    else if (cur != prev) { ranges[prev].y = (uint32_t)i; ranges[cur].x = (uint32_t)i; }
+    if (i == L - 1) ranges[cur].y = (uint32_t)L;
+    prev = cur;
+  }
 }
 
 // Batch-level culling.  While a batch of 64 list entries is staged, lane k still has entry k's
