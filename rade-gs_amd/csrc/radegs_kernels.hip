@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, const uint32
     const unsigned long long sq = tile_sq_sum ? *tile_sq_sum : 0ull;   // PIN_SQ_LO / PIN_SQ_HI (rg_launch.inc)
     __hip_atomic_store(count_mirror + 6, (uint32_t)sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(count_mirror + 7, (uint32_t)(sq >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // PIN_SEQ; a stream forward publishes it later, together with the chunks its lists took (balance_blocks_kernel)
+    // PIN_SEQ; a stream forward publishes it later, together with the chunks its lists took (block_lists_kernel)
     if (!MASKS) __hip_atomic_store(count_mirror + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (i == 0) {   // does this image state hold entry streams?  (ImageState::stream_tag; the chunk allocator and its overflow flag start at 0)

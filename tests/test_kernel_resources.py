@@ -72,9 +72,8 @@ BUDGET = [
     (("preprocess_fwd_kernelILb0E",), 5, 0, 0),                      # 5 since round 6: all 48 SH coefficients in flight at once (one round trip
                                                                      # instead of four; same-box A/B against two batches at 6 waves: 0.094 | 0.096 ms)
     (("preprocess_bwd_kernel",), 3, 16, 0),                          # dynamic LDS: the SH slab
-    (("block_lists_kernelILb0E",), 8, 0, 256),
+    (("block_lists_kernelILb0E",), 8, 0, 4352),                      # 4 KB of it: the block-balancing sort its first workgroups run (round 6)
     (("block_counts_kernelILb0E",), 8, 0, 512),
-    (("balance_blocks_kernel",), 8, 0, 4096),
     (("emit_instances_kernelILb1E",), 6, 0, 0),
     (("tile_ranges_kernelItE",), 8, 0, 0),
     (("integrate_kernel",), 5, 0, 16384),
