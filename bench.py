@@ -217,7 +217,7 @@ def main():
     # are 7 ms.  Throughput is a steady-state quantity (a training run is thousands of iterations), so the same step is repeated, untimed,
     # until `--settle-ms` of GPU work have gone by; the timed K steps follow the usual barrier + synchronize.  Nothing inside the timed
     # region changes.
-    n_settle = 0
+    n_settle, settle_ms_per_step = 0, None
     if args.settle_ms > 0 and args.warmup > 0:
         # how many: from the duration of the first four, the SAME count on every rank (under the launcher a step ends with a collective:
         # ranks that counted by their own clocks would issue different numbers of them and hang)
@@ -235,6 +235,7 @@ def main():
         for _ in range(n_settle - 4):
             R, radii, _ = step()
         fence()
+        settle_ms_per_step = (time.perf_counter() - t_s) * 1e3 / n_settle   # what these steps -- the first after the warm-up -- took
     # the dominant kernel is timed live on every 2nd step of the timed region (the event pair around it is a ~12 us stream bubble;
     # every 2nd step of a 9-view rotation still visits every view)
     C.profile_enable(True, only=dom, every=2 if (dom is not None and args.steps >= 8) else 1)   # no warm-up steps: every stage, in the timed region
@@ -331,9 +332,10 @@ def main():
                               "achieved_GBs_gpu_time": round(ab["total"] / (gpu_ms * 1e-3) / 1e9, 1) if gpu_ms > 0 else 0.0,
                               "achieved_GBs_wall": round(ab["total"] / (ms_per_step * 1e-3) / 1e9, 1),
                               "frac_wall": round(ab["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-            "settle": {"untimed_steps": n_settle, "ms": args.settle_ms,
+            "settle": {"untimed_steps": n_settle, "ms": args.settle_ms, "ms_per_step_during_settle": None if settle_ms_per_step is None else round(settle_ms_per_step, 4),
                        "note": "untimed repetitions of the step between the W warm-up steps and the timed region, until the GPU has worked for `ms`: "
-                               "its clock settles only after ~20 ms of continuous work (first steps after an idle period run ~10 % slow)"},
+                               "its clock settles only after ~20 ms of continuous work (first steps after an idle period run ~10 % slow); "
+                               "ms_per_step_during_settle = wall clock of these very steps, i.e. what a line without them would read"},
             "step_gpu_span_ms": {"median": round(spans[len(spans) // 2], 4), "min": round(spans[0], 4), "max": round(spans[-1], 4), "mean": round(sum(spans) / len(spans), 4), "in_step_order": [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(args.steps)],
                                  "note": "HIP-event spans between consecutive steps on the launch stream; ms_per_step is the wall clock of the whole region / steps; "
                                          "Python's cyclic GC is collected before and disabled during the timed region (a gen-2 pass is a 5-30 ms host stall)"},

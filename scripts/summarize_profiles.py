@@ -36,7 +36,10 @@ for name in ("pmc_sq", "pmc_tcc", "pmc_clk"):
             # (round 3's summaries cut at the first "(", which merged every kernel of the sort's anonymous namespace into "void rg::")
             nm = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
             per_kernel[(nm, r["Counter_Name"])].append(float(r["Counter_Value"]))
-    steps_in_run = int(os.environ.get("PMC_RUN_STEPS", "18"))     # scripts/gpu_profile.sh: --steps 9 --warmup 9
+    # steps of the profiled run = dispatches of a kernel that runs exactly once per step (the bench's warm-up, clock-settling and timed
+    # steps all count: 9 + 9 + the `settle` repetitions since round 6); PMC_RUN_STEPS overrides
+    once = [len(v) for (k, c), v in per_kernel.items() if "preprocess_fwd_kernel" in k or "points_preprocess_kernel" in k]
+    steps_in_run = int(os.environ.get("PMC_RUN_STEPS", "0")) or (max(once) if once else 18)
     for (k, c), vals in per_kernel.items():
         agg[k][c] = vals[len(vals) // 2:]
         out.setdefault(k, {})["dispatches_per_step"] = round(len(vals) / steps_in_run, 3)
