@@ -230,7 +230,10 @@ __global__ void __launch_bounds__(kSortThreads) scatter_kernel(const K* __restri
 
 // ---- inclusive scan of tiles_touched gathered through idx_sorted: block sums, then a scan in which every block first adds up the
 // sums of the blocks before it (two launches) ----
-constexpr int kScanItems = 16;  // per thread -> 4096 per block
+// items per thread of the two scan kernels: 16 (4 096 per block), or 4 for up to 2 M items -- 245 blocks of 4 096 are ONE workgroup per CU
+// for a kernel that is nothing but latency (C2: scan 0.026 -> 0.020 ms); every block adds up the sums of the blocks before it, which is
+// quadratic in their number, hence the cap
+constexpr int kScanItemsMax = 16;
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
   __shared__ uint32_t ws[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -255,7 +258,7 @@ __device__ __forceinline__ uint32_t rect_count(uint32_t r) { return ((r >> 16) &
 
 // sq_part != nullptr: sq_part[block] = sum of (count^2) over the block's items; gather_scan_kernel's last block adds the partial sums up
 // (the launcher's splat-size statistic, rg_launch.inc::use_streams -- no atomics: 1 000 same-address atomics cost 10 us here).
-template <bool PACKED>
+template <bool PACKED, int kScanItems>
 __global__ void __launch_bounds__(kSortThreads) gather_block_sums_kernel(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ idx,
                                                                          uint32_t n, uint32_t* __restrict__ block_sums,
                                                                          uint32_t* __restrict__ gathered, unsigned long long* __restrict__ sq_part) {
@@ -293,7 +296,7 @@ __global__ void __launch_bounds__(kSortThreads) gather_block_sums_kernel(const u
   if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-template <bool PACKED>
+template <bool PACKED, int kScanItems>
 __global__ void __launch_bounds__(kSortThreads) gather_scan_kernel(const uint32_t* __restrict__ gathered, uint32_t n,
                                                                    const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ out,
                                                                    const unsigned long long* __restrict__ sq_part,
@@ -423,9 +426,10 @@ hipError_t radix_sort_pairs_u16(void* temp, size_t temp_bytes, const uint16_t* k
 }  // namespace rg
 
 namespace rg {
+static int scan_items_per_thread(size_t n) { return n <= (size_t(2) << 20) ? 4 : kScanItemsMax; }
 size_t scan_temp_bytes(size_t n) {   // block sums (u32) + partial sums of squares (u64) per block, then the gathered copy
-  return ((n + kSortThreads * kScanItems - 1) / (kSortThreads * kScanItems) + 64) * (sizeof(uint32_t) + sizeof(unsigned long long)) + 1024 +
-         n * sizeof(uint32_t);
+  const size_t per_block = (size_t)kSortThreads * scan_items_per_thread(n);
+  return ((n + per_block - 1) / per_block + 64) * (sizeof(uint32_t) + sizeof(unsigned long long)) + 1024 + n * sizeof(uint32_t);
 }
 
 // out[i] = sum_{j <= i} vals[idx[j]]   (rasterizer_impl.cu:350's InclusiveSum, taken in depth order); idx == nullptr: identity
@@ -435,16 +439,23 @@ hipError_t inclusive_scan_gather_u32(void* temp, size_t temp_bytes, const uint32
                                      hipStream_t stream, uint32_t* packed_out, unsigned long long* sq_sum) {
   if (n == 0) return hipSuccess;
   if (temp_bytes < scan_temp_bytes(n)) return hipErrorInvalidValue;
-  const uint32_t nblocks = (uint32_t)((n + kSortThreads * kScanItems - 1) / (kSortThreads * kScanItems));
+  const int items = scan_items_per_thread(n);
+  const uint32_t nblocks = (uint32_t)((n + (size_t)kSortThreads * items - 1) / ((size_t)kSortThreads * items));
   const uint32_t nb64 = (nblocks + 64) & ~63u;
   unsigned long long* sq_part = static_cast<unsigned long long*>(temp);                // [nb64] (8-byte aligned: first in the buffer)
   uint32_t* block_sums = reinterpret_cast<uint32_t*>(sq_part + nb64);                  // [nb64]
   uint32_t* gathered = packed_out ? packed_out : block_sums + nb64;
   if (!sq_sum) sq_part = nullptr;
-  if (packed_out) hipLaunchKernelGGL(gather_block_sums_kernel<true>, dim3(nblocks), dim3(kSortThreads), 0, stream, vals, idx, (uint32_t)n, block_sums, gathered, sq_part);
-  else hipLaunchKernelGGL(gather_block_sums_kernel<false>, dim3(nblocks), dim3(kSortThreads), 0, stream, vals, idx, (uint32_t)n, block_sums, gathered, sq_part);
-  if (packed_out) hipLaunchKernelGGL(gather_scan_kernel<true>, dim3(nblocks), dim3(kSortThreads), 0, stream, gathered, (uint32_t)n, block_sums, out, sq_part, sq_sum);
-  else hipLaunchKernelGGL(gather_scan_kernel<false>, dim3(nblocks), dim3(kSortThreads), 0, stream, gathered, (uint32_t)n, block_sums, out, sq_part, sq_sum);
+#define RG_SCAN_LAUNCH(P_, I_)                                                                                                                      \
+  do {                                                                                                                                               \
+    hipLaunchKernelGGL((gather_block_sums_kernel<P_, I_>), dim3(nblocks), dim3(kSortThreads), 0, stream, vals, idx, (uint32_t)n, block_sums, gathered, \
+                       sq_part);                                                                                                                     \
+    hipLaunchKernelGGL((gather_scan_kernel<P_, I_>), dim3(nblocks), dim3(kSortThreads), 0, stream, gathered, (uint32_t)n, block_sums, out, sq_part,     \
+                       sq_sum);                                                                                                                      \
+  } while (0)
+  if (packed_out) { if (items == 4) RG_SCAN_LAUNCH(true, 4); else RG_SCAN_LAUNCH(true, kScanItemsMax); }
+  else { if (items == 4) RG_SCAN_LAUNCH(false, 4); else RG_SCAN_LAUNCH(false, kScanItemsMax); }
+#undef RG_SCAN_LAUNCH
   return hipGetLastError();
 }
 }  // namespace rg
